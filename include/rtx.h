@@ -1,0 +1,245 @@
+/*
+ * rtx.h — C ABI of the MI355X renderer core.
+ *
+ * The reference renderer has no FFI layer; its seam is the object boundary between
+ * RayTracer (RTBase/Renderer.h) and Scene / Film (RTBase/Scene.h, RTBase/Imaging.h).
+ * Every entry point below names the reference interface it stands in for.
+ *
+ * Conventions
+ *   - every function returns 0 (RTX_OK) or a negative RTX_ERR_* code; rtx_last_error()
+ *     gives the message of the last failure on the calling thread
+ *   - handles are opaque; host pointers are borrowed for the duration of the call only
+ *   - one context drives one GPU; one host thread per context (the reference's caller,
+ *     RTBase/Main.cpp:129-221, is single threaded as well)
+ *   - all arithmetic is fp32 as in the reference; matrices are row-major float[16]
+ *     (RTBase/Core.h:217-224)
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTX_OK 0
+#define RTX_ERR_INVALID (-1) /* bad argument / shape mismatch            */
+#define RTX_ERR_HIP     (-2) /* a HIP runtime call failed                */
+#define RTX_ERR_STATE   (-3) /* call order violated (e.g. no scene yet)  */
+#define RTX_ERR_NOMEM   (-4) /* host or device allocation failed         */
+
+typedef struct rtx_ctx rtx_ctx;
+
+/* ---- plain data ------------------------------------------------------------------- */
+
+/* Ray origin + direction. The reciprocal direction of RTBase/Geometry.h:25 is recomputed
+ * on the device with the same three IEEE divides. */
+typedef struct { float o[3]; float d[3]; } rtx_ray;
+
+/* IntersectionData, RTBase/Geometry.h:276-283. On a miss t == FLT_MAX and
+ * id == 0xFFFFFFFF (the reference leaves ID uninitialised there). */
+typedef struct { uint32_t id; float t, alpha, beta, gamma; } rtx_hit;
+
+/* ALGORITHM / DRAW_MODE, RTBase/Settings.h:3-16; IMAGE_FILTER, RTBase/Imaging.h:16-21 */
+enum { RTX_AL_PATH_TRACE = 0, RTX_AL_LIGHT_TRACE = 1, RTX_AL_INSTANT_RADIOSITY = 2 };
+enum { RTX_DM_ALGORITHM = 0, RTX_DM_NORMALS = 1, RTX_DM_ALBEDO = 2, RTX_DM_DIRECT = 3 };
+enum { RTX_FT_BOX = 0, RTX_FT_GAUSSIAN = 1, RTX_FT_MITCHELL_NETRAVALI = 2 };
+
+/* BSDF kinds, RTBase/Materials.h:139-678 (the material factory is
+ * RTBase/SceneLoader.h:212-272). */
+enum {
+    RTX_BSDF_DIFFUSE   = 0, /* DiffuseBSDF   Materials.h:139 */
+    RTX_BSDF_MIRROR    = 1, /* MirrorBSDF    Materials.h:179 */
+    RTX_BSDF_CONDUCTOR = 2, /* ConductorBSDF Materials.h:234 ("Glossy") */
+    RTX_BSDF_GLASS     = 3, /* GlassBSDF     Materials.h:351 */
+    RTX_BSDF_PLASTIC   = 4  /* PlasticBSDF   Materials.h:564 */
+};
+
+/* One material. `roughness` is the constructor argument of the reference classes
+ * (alpha = 1.62142*sqrt(roughness), Materials.h:248,582); emission > 0 luminance makes
+ * every triangle that uses the material an area light (Scene.h:101-110). */
+typedef struct {
+    int32_t type;
+    int32_t texture;     /* index into rtx_scene_desc.textures (albedo / reflectance) */
+    float emission[3];
+    float eta[3];        /* conductor */
+    float k[3];          /* conductor */
+    float roughness;     /* conductor, plastic */
+    float int_ior;       /* glass, plastic */
+    float ext_ior;       /* glass, plastic */
+} rtx_material;
+
+/* Texture texels as the reference keeps them after load: float RGB, row-major
+ * (RTBase/Imaging.h:50-67). */
+typedef struct { int32_t width, height; const float* rgb; } rtx_texture;
+
+/* Scene hand-over: what Scene::init + Scene::build (RTBase/Scene.h:94-110,151-169) receive,
+ * as structure-of-arrays. Triangle i has vertices positions[i*9 + 3*k .. +2], k = 0..2.
+ * env_rgb == NULL selects BackgroundColour(background) (RTBase/Lights.h:86), otherwise an
+ * EnvironmentMap (RTBase/Lights.h:307) over env_width x env_height float RGB texels. */
+typedef struct {
+    uint64_t n_triangles;
+    const float* positions;          /* [n][3][3] */
+    const float* normals;            /* [n][3][3] */
+    const float* uvs;                /* [n][3][2] */
+    const uint32_t* material_index;  /* [n]       */
+    uint32_t n_materials;
+    const rtx_material* materials;
+    uint32_t n_textures;
+    const rtx_texture* textures;
+    int32_t env_width, env_height;
+    const float* env_rgb;
+    float background[3];
+} rtx_scene_desc;
+
+/* Camera state exactly as RTBase/Scene.h:10-41 holds it. */
+typedef struct {
+    float proj[16];            /* projectionMatrix                */
+    float inv_proj[16];        /* inverseProjectionMatrix         */
+    float camera[16];          /* camera (view-to-world)          */
+    float camera_to_view[16];  /* cameraToView (world-to-view)    */
+    float origin[3];
+    float view_dir[3];
+    float afilm;
+    int32_t width, height;
+} rtx_camera;
+
+/* SETTINGS, RTBase/Settings.h:18-62, plus the counter-RNG seed and the multi-GPU shard.
+ * shard_mode 0: this context renders everything; 1: 16x16 tiles t with
+ * t % shard_world == shard_rank; 2: every pixel, and sample indices s with
+ * s % shard_world == shard_rank (the caller sums films across ranks). */
+typedef struct {
+    int32_t algorithm, draw_mode, filter;
+    int32_t use_mis, can_hit_light, adaptive_sampling;
+    uint32_t max_bounces, init_spp, total_spp;
+    uint32_t vpl_rays_per_tile, num_threads; /* VPL light paths per pass = product, Renderer.h:174 */
+    uint32_t seed;
+    int32_t shard_mode, shard_rank, shard_world;
+} rtx_settings;
+
+typedef struct {
+    uint64_t closest_rays;     /* rays through the closest-hit kernel since create/reset */
+    uint64_t shadow_rays;      /* rays through the visibility kernel                      */
+    uint64_t samples;          /* pixel samples started                                   */
+    uint32_t bvh2_nodes, bvh2_depth, bvh4_nodes, bvh4_depth, n_lights;
+    float build_ms;            /* host BVH build + flatten                                */
+} rtx_stats;
+
+/* ---- context ---------------------------------------------------------------------- */
+
+/* No reference counterpart (the reference is CPU only): binds a context to GPU `device`
+ * and creates its stream. */
+int rtx_create(rtx_ctx** out, int device);
+void rtx_destroy(rtx_ctx* ctx);
+const char* rtx_last_error(void);
+
+/* Work is enqueued on `hip_stream` (a hipStream_t) instead of the context's own stream;
+ * NULL restores the own stream. For callers that time or order work themselves. */
+int rtx_set_stream(rtx_ctx* ctx, void* hip_stream);
+int rtx_synchronize(rtx_ctx* ctx);
+
+/* ---- scene / camera / settings ---------------------------------------------------- */
+
+/* Scene::init + Scene::build, RTBase/Scene.h:94-110,151-169 and BVHTree::build,
+ * RTBase/Geometry.h:458-504: builds the reference's binary SAH tree on the host
+ * (identical topology and leaf order), flattens it into the 4-wide device layout and
+ * uploads triangles, materials, textures, lights and the environment tables
+ * (TabulatedDistribution::init, RTBase/Lights.h:161-208). Triangles of zero area must
+ * already be dropped (RTBase/SceneLoader.h:330). */
+int rtx_upload_scene(rtx_ctx* ctx, const rtx_scene_desc* scene);
+
+/* loadScene's camera set-up, RTBase/SceneLoader.h:342-360 + Camera::init/updateView,
+ * RTBase/Scene.h:22-41: perspective(0.001, 10000, w/h, fov), lookAt(from,to,up).invert(). */
+int rtx_camera_look_at(rtx_camera* out, const float from[3], const float to[3], const float up[3],
+                       float fov_deg, int width, int height, int flip_x);
+int rtx_set_camera(rtx_ctx* ctx, const rtx_camera* cam);
+
+/* RayTracer::init's settings hand-over, RTBase/Renderer.h:69-87 (adaptive sampling is
+ * gated to path tracing there; initSPP falls back to totalSPP without it). */
+int rtx_set_settings(rtx_ctx* ctx, const rtx_settings* s);
+
+/* ---- progressive rendering -------------------------------------------------------- */
+
+/* RayTracer::clear, RTBase/Renderer.h:117 → Film::clear, RTBase/Imaging.h:397. */
+int rtx_clear(rtx_ctx* ctx);
+
+/* n calls of RayTracer::renderMT, RTBase/Renderer.h:753-782: each pass adds one sample
+ * per active pixel (or one light path per pixel for light tracing), and after the pass
+ * in which SPP == initSPP computes the adaptive per-tile sample targets
+ * (calculateTileSamples, RTBase/Renderer.h:643-671). Blocking. */
+int rtx_render_passes(rtx_ctx* ctx, int n_passes);
+
+/* RayTracer::getSPP, RTBase/Renderer.h:856. */
+int rtx_get_spp(rtx_ctx* ctx, int* spp);
+
+/* Film::film / Film::SPP / RayTracer::tileSamples as the host reads them
+ * (RTBase/Imaging.h:299-302, RTBase/Renderer.h:41): accumulated RGB sums [H][W][3].
+ * tile_samples may be NULL; otherwise it receives ceil(W/16)*ceil(H/16) entries. */
+int rtx_film_read(rtx_ctx* ctx, float* rgb_sums, int* spp, uint32_t* tile_samples);
+
+/* Device address of the film accumulator (W*H*3 floats) and of the tile-sample table, for
+ * callers that combine films across GPUs with a collective (no reference counterpart). */
+int rtx_film_device(rtx_ctx* ctx, void** film_dev, size_t* n_floats);
+int rtx_tile_samples_device(rtx_ctx* ctx, void** tiles_dev, size_t* n_tiles);
+/* Recompute the adaptive tile targets from the film as it stands (after a cross-GPU sum),
+ * calculateTileSamples, RTBase/Renderer.h:643-671. */
+int rtx_update_tile_samples(rtx_ctx* ctx);
+/* Overwrite SPP (after a cross-GPU sum of films rendered with shard_mode 2). */
+int rtx_set_spp(rtx_ctx* ctx, int spp);
+
+/* ---- ray queries ------------------------------------------------------------------ */
+
+/* Scene::traverse, RTBase/Scene.h:137-141 → BVHTree::traverse, RTBase/Geometry.h:506-566,
+ * for n rays in host memory. */
+int rtx_trace_closest(rtx_ctx* ctx, const rtx_ray* rays, size_t n, rtx_hit* hits);
+/* Same, rays and hits already in device memory (no copies, asynchronous on the stream). */
+int rtx_trace_closest_device(rtx_ctx* ctx, const rtx_ray* rays_dev, size_t n, rtx_hit* hits_dev);
+
+/* Scene::visible, RTBase/Scene.h:170-178 → BVHTree::traverseVisible,
+ * RTBase/Geometry.h:568-610, for n segments p1→p2 (6 floats each); visible[i] is 1 or 0. */
+int rtx_trace_visible(rtx_ctx* ctx, const float* p1p2, size_t n, uint8_t* visible);
+int rtx_trace_visible_device(rtx_ctx* ctx, const float* p1p2_dev, size_t n, uint8_t* visible_dev);
+
+/* Camera::generateRay, RTBase/Scene.h:49-59, at the pixel centres (x+0.5, y+0.5) of the
+ * whole film, written to device memory in the core's 8x8-tile queue order; pixel_dev[i]
+ * (may be NULL) receives y*W+x of ray i. n_capacity must be >= W*H. */
+int rtx_generate_primary_rays_device(rtx_ctx* ctx, rtx_ray* rays_dev, uint32_t* pixel_dev,
+                                     size_t n_capacity);
+
+/* ---- introspection ---------------------------------------------------------------- */
+
+/* The binary tree exactly as BVHTree keeps it (RTBase/Geometry.h:293-304): per node
+ * bounds_min[3], bounds_max[3], start, end, child_l, child_r; and the index permutation.
+ * Pass NULL arrays to query the counts only. */
+int rtx_get_bvh(rtx_ctx* ctx, uint32_t* n_nodes, float* bounds /*[n][6]*/,
+                uint32_t* topo /*[n][4]*/, uint32_t* indices /*[n_triangles]*/);
+
+/* The same tree without a GPU: runs only the host-side build of rtx_upload_scene
+ * (BVHTree::build, RTBase/Geometry.h:458-504) and keeps the result in an opaque handle.
+ * wide_nodes / wide_depth describe the flattened 4-wide layout. */
+typedef struct rtx_host_bvh rtx_host_bvh;
+int rtx_host_bvh_build(const rtx_scene_desc* scene, rtx_host_bvh** out);
+int rtx_host_bvh_get(const rtx_host_bvh* h, uint32_t* n_nodes, uint32_t* depth, float* bounds /*[n][6]*/,
+                     uint32_t* topo /*[n][4]*/, uint32_t* indices, uint32_t* wide_nodes, uint32_t* wide_depth);
+void rtx_host_bvh_free(rtx_host_bvh* h);
+
+int rtx_get_stats(rtx_ctx* ctx, rtx_stats* out);
+int rtx_reset_stats(rtx_ctx* ctx);
+
+/* hipEvent pair on the context's current stream: elapsed GPU time of the work enqueued
+ * between the two calls, in milliseconds. */
+int rtx_timer_begin(rtx_ctx* ctx);
+int rtx_timer_end(rtx_ctx* ctx, float* ms);
+
+/* Algorithmic traffic of the closest-hit kernel for the rays of the last
+ * rtx_trace_closest* call, counted by an instrumented device pass over the same layout:
+ * wide nodes visited (128 B each) and triangles tested (48 B each), summed over rays. */
+int rtx_count_closest_work(rtx_ctx* ctx, const rtx_ray* rays_dev, size_t n,
+                           uint64_t* nodes_visited, uint64_t* tris_tested);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H */

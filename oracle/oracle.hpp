@@ -1,0 +1,391 @@
+// oracle.hpp — CPU restatement of the reference renderer's per-pixel hot path.
+//
+// TEST INFRASTRUCTURE ONLY. Nothing in the product (ray-tracer_amd/, include/) includes,
+// links or calls this file; it exists so that tests/, __graft_entry__.smoke() and the
+// cpu_baseline leg of bench.py can check the HIP path and time a CPU baseline.
+//
+// Parity status: PARITY UNPINNED except for the three AABB known-answer cases of the
+// reference's own unit tests (UnitTests/test.cpp:3-34) and for the math / sampling layer,
+// which is checked against the real RTBase/Core.h + RTBase/Sampling.h compiled into
+// oracle/_ref (those two headers build on Linux as they are). The rest of the reference
+// cannot be built here: RTBase/Geometry.h:5 includes <conio.h>, RTBase/Renderer.h:10 a
+// Win32/D3D11 window header and RTBase/Imaging.h:7 forces the MSVC-only sprintf_s path, and
+// the reference ships no golden outputs for this path. Every function below therefore
+// follows the reference text operation by operation and cites the lines it restates.
+//
+// Arithmetic is fp32 with the reference's operation order; build with -ffp-contract=off
+// and without -ffast-math so that no multiply-add is fused.
+#pragma once
+
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "../include/rtx.h"
+#include "../include/rtx_rng.h"
+
+namespace orc {
+
+// Windows <minwindef.h> function-like macros the reference's Renderer.h relies on
+// (RTBase/Renderer.h:92,156,237,...): note the NaN behaviour (second operand wins).
+template <class A, class B> static inline auto wmin(A a, B b) -> decltype(a < b ? a : b) { return (a < b) ? a : b; }
+template <class A, class B> static inline auto wmax(A a, B b) -> decltype(a > b ? a : b) { return (a > b) ? a : b; }
+
+static constexpr float kEps = 0.001f;     // EPSILON, RTBase/Geometry.h:54
+static constexpr float kTriEps = 1e-8f;   // Triangle::epsilon, RTBase/Geometry.h:72
+static constexpr double kPi = 3.14159265358979323846; // M_PI (a double in the reference)
+
+// ---------------------------------------------------------------------------------------
+// L0 math — RTBase/Core.h
+// ---------------------------------------------------------------------------------------
+struct V3 { float x = 0, y = 0, z = 0; };                       // Vec3, Core.h:107-186 (w unused on the path)
+static inline V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+static inline V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }   // Core.h:140
+static inline V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }   // Core.h:144
+static inline V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }       // Core.h:148
+static inline V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }   // Core.h:156
+static inline V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }                         // Core.h:164
+static inline float dot(V3 a, V3 b) { return ((a.x * b.x) + (a.y * b.y) + (a.z * b.z)); } // Core.h:178,188
+static inline V3 cross(V3 a, V3 b)                                                         // Core.h:182,194
+{ return v3((a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x)); }
+static inline float lengthSq(V3 a) { return ((a.x * a.x) + (a.y * a.y) + (a.z * a.z)); } // Core.h:165
+static inline float length(V3 a) { return sqrtf((a.x * a.x) + (a.y * a.y) + (a.z * a.z)); } // Core.h:169
+static inline V3 normalize(V3 a)                                                           // Core.h:173
+{ float l = 1.0f / sqrtf((a.x * a.x) + (a.y * a.y) + (a.z * a.z)); return v3(a.x * l, a.y * l, a.z * l); }
+static inline V3 vmax(V3 a, V3 b) { return v3(a.x > b.x ? a.x : b.x, a.y > b.y ? a.y : b.y, a.z > b.z ? a.z : b.z); } // Core.h:199
+static inline V3 vmin(V3 a, V3 b) { return v3(a.x < b.x ? a.x : b.x, a.y < b.y ? a.y : b.y, a.z < b.z ? a.z : b.z); } // Core.h:204
+static inline float comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+struct RGB { float r = 0, g = 0, b = 0; };                      // Colour, Core.h:22-105
+static inline RGB rgb(float r, float g, float b) { RGB c; c.r = r; c.g = g; c.b = b; return c; }
+static inline RGB operator+(RGB a, RGB b) { return rgb(a.r + b.r, a.g + b.g, a.b + b.b); }
+static inline RGB operator-(RGB a, RGB b) { return rgb(a.r - b.r, a.g - b.g, a.b - b.b); }
+static inline RGB operator*(RGB a, RGB b) { return rgb(a.r * b.r, a.g * b.g, a.b * b.b); }
+static inline RGB operator/(RGB a, RGB b) { return rgb(a.r / b.r, a.g / b.g, a.b / b.b); }
+static inline RGB operator*(RGB a, float v) { return rgb(a.r * v, a.g * v, a.b * v); }
+static inline RGB operator/(RGB a, float v) { return rgb(a.r / v, a.g / v, a.b / v); }
+static inline float lum(RGB c) { return ((0.2126f * c.r) + (0.7152f * c.g) + (0.0722f * c.b)); } // Core.h:101
+
+struct M4 {                                                       // Matrix, Core.h:217-517 (row-major)
+    float m[16];
+    M4() { std::memset(m, 0, sizeof m); m[0] = m[5] = m[10] = m[15] = 1.0f; }
+};
+static inline V3 mulVec(const M4& a, V3 v)                        // Core.h:307
+{ return v3((v.x * a.m[0] + v.y * a.m[1] + v.z * a.m[2]), (v.x * a.m[4] + v.y * a.m[5] + v.z * a.m[6]), (v.x * a.m[8] + v.y * a.m[9] + v.z * a.m[10])); }
+static inline V3 mulPoint(const M4& a, V3 v)                      // Core.h:314
+{ return v3((v.x * a.m[0] + v.y * a.m[1] + v.z * a.m[2]) + a.m[3], (v.x * a.m[4] + v.y * a.m[5] + v.z * a.m[6]) + a.m[7], (v.x * a.m[8] + v.y * a.m[9] + v.z * a.m[10]) + a.m[11]); }
+static inline V3 mulPointDivide(const M4& a, V3 v)                // Core.h:322
+{
+    V3 v1 = mulPoint(a, v);
+    float w = (a.m[12] * v.x) + (a.m[13] * v.y) + (a.m[14] * v.z) + a.m[15];
+    w = 1.0f / w;
+    return v1 * w;
+}
+// cofactor expansion, Core.h:338-450 (row r, column c of the adjugate, same term order)
+static inline M4 invert(const M4& A)
+{
+    const float* m = A.m; M4 R; float* inv = R.m;
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    if (det == 0) { return M4(); }   // reference resets itself to identity and returns the (unscaled) adjugate; unreachable for camera matrices
+    det = 1.0f / det;
+    for (int i = 0; i < 16; i++) inv[i] = inv[i] * det;
+    return R;
+}
+static inline M4 lookAt(V3 from, V3 to, V3 up)                    // Core.h:451-471
+{
+    M4 mat;
+    V3 dir = normalize(from - to);
+    V3 left = normalize(cross(up, dir));
+    V3 newUp = cross(dir, left);
+    mat.m[0] = left.x;  mat.m[1] = left.y;  mat.m[2] = left.z;
+    mat.m[4] = newUp.x; mat.m[5] = newUp.y; mat.m[6] = newUp.z;
+    mat.m[8] = dir.x;   mat.m[9] = dir.y;   mat.m[10] = dir.z;
+    mat.m[3] = -dot(from, left);
+    mat.m[7] = -dot(from, newUp);
+    mat.m[11] = -dot(from, dir);
+    mat.m[15] = 1;
+    return mat;
+}
+static inline M4 perspective(float n, float f, float aspect, float fov) // Core.h:472-483
+{
+    M4 p; std::memset(p.m, 0, sizeof p.m);
+    float t = 1.0f / (tanf(fov * 0.5f * 3.141592654f / 180.0f));
+    p.m[0] = t / aspect;
+    p.m[5] = t;
+    p.m[10] = -f / (f - n);
+    p.m[11] = -(f * n) / (f - n);
+    p.m[14] = -1.0f;
+    return p;
+}
+
+struct Frame {                                                    // Frame, Core.h:519-555
+    V3 u, v, w;
+    void fromVector(V3 n)
+    {
+        w = normalize(n);
+        if (fabsf(w.x) > fabsf(w.y)) { float l = 1.0f / sqrtf(w.x * w.x + w.z * w.z); u = v3(w.z * l, 0.0f, -w.x * l); }
+        else { float l = 1.0f / sqrtf(w.y * w.y + w.z * w.z); u = v3(0, w.z * l, -w.y * l); }
+        v = cross(w, u);
+    }
+    V3 toLocal(V3 a) const { return v3(dot(a, u), dot(a, v), dot(a, w)); }
+    V3 toWorld(V3 a) const { return ((u * a.x) + (v * a.y) + (w * a.z)); }
+};
+
+// ---------------------------------------------------------------------------------------
+// Samplers — RTBase/Sampling.h
+// ---------------------------------------------------------------------------------------
+struct Sampler { virtual float next() = 0; virtual ~Sampler() {} };    // Sampling.h:7-11
+
+struct MTSampler : Sampler {                                      // MTRandom, Sampling.h:13-29
+    std::mt19937 gen; std::uniform_real_distribution<float> dist{0.0f, 1.0f};
+    explicit MTSampler(unsigned seed = 1) { gen.seed(seed); }
+    float next() override { float r = dist(gen); return r < 1e-8f ? 1e-8f : r; }
+};
+
+// The core's counter sampler (include/rtx_rng.h): call d of next() = rtx_rng_float(key, d).
+struct CounterSampler : Sampler {
+    uint32_t key = 0, dim = 0;
+    CounterSampler() {}
+    CounterSampler(uint32_t seed, uint32_t stream, uint32_t item, uint32_t sample) { reset(seed, stream, item, sample); }
+    void reset(uint32_t seed, uint32_t stream, uint32_t item, uint32_t sample) { key = rtx_rng_key(seed, stream, item, sample); dim = 0; }
+    float next() override { return rtx_rng_float(key, dim++); }
+};
+
+// SamplingDistributions, Sampling.h:32-73 (z-up). 2.0f * M_PI * r2 is evaluated in double.
+static inline V3 cosineSampleHemisphere(float r1, float r2)       // Sampling.h:48
+{
+    float cosTheta = sqrtf(r1);
+    float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+    float phi = (float)(2.0f * kPi * r2);
+    return v3(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta);
+}
+static inline float cosineHemispherePDF(V3 wi) { return (float)(fabsf(wi.z) / kPi); }    // Sampling.h:56
+static inline V3 uniformSampleSphere(float r1, float r2)          // Sampling.h:61
+{
+    float cosTheta = 1.0f - 2.0f * r1;
+    float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+    float phi = (float)(2.0f * kPi * r2);
+    return v3(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta);
+}
+static inline float uniformSpherePDF() { return (float)(1.0f / (4.0f * kPi)); }           // Sampling.h:69
+// Call sites write f(sampler->next(), sampler->next()) (Materials.h:150,610; Lights.h:78,96,
+// 123,131,398,409). Argument evaluation order is unspecified; g++ and MSVC x64 both evaluate
+// right to left, so the FIRST draw feeds r2. Spelled out here so every compiler agrees.
+#define ORC_DRAW_R2_THEN_R1(s, r1, r2) float r2 = (s)->next(); float r1 = (s)->next()
+
+// ---------------------------------------------------------------------------------------
+// L1 geometry — RTBase/Geometry.h
+// ---------------------------------------------------------------------------------------
+struct Ray {                                                      // Geometry.h:8-31
+    V3 o, dir, invDir;
+    Ray() {}
+    Ray(V3 o_, V3 d_) { init(o_, d_); }
+    void init(V3 o_, V3 d_) { o = o_; dir = d_; invDir = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z); }
+    V3 at(float t) const { return (o + (dir * t)); }
+};
+
+struct Vtx { V3 p, normal; float u = 0, v = 0; };                 // Vertex, Core.h:209-215
+
+struct Tri {                                                      // Triangle, Geometry.h:56-162
+    Vtx vertices[3]; V3 e1, e2, n; float area = 0, d = 0; unsigned materialIndex = 0; V3 centre, maxP, minP;
+    void init(const Vtx& v0, const Vtx& v1, const Vtx& v2, unsigned mat)         // Geometry.h:74-92
+    {
+        materialIndex = mat; vertices[0] = v0; vertices[1] = v1; vertices[2] = v2;
+        e1 = vertices[0].p - vertices[2].p;
+        e2 = vertices[1].p - vertices[2].p;
+        n = normalize(cross(e1, e2));
+        d = dot(n, vertices[0].p);
+        area = length(cross(e1, e2)) * 0.5f;
+        maxP = vmax(vertices[0].p, vmax(vertices[1].p, vertices[2].p));
+        minP = vmin(vertices[0].p, vmin(vertices[1].p, vertices[2].p));
+        centre = minP + (maxP - minP) * 0.5f;
+    }
+    bool rayIntersect(const Ray& r, float& t, float& u, float& v) const            // Geometry.h:95-126
+    {
+        V3 p = cross(r.dir, e2);
+        float det = dot(p, e1);
+        if (std::fabs(det) < kTriEps) return false;
+        float invDet = 1.0f / det;
+        V3 T = r.o - vertices[2].p;
+        u = dot(T, p) * invDet;
+        if ((u < 0 && std::fabs(u) > kTriEps) || (u > 1 && std::fabs(u - 1) > kTriEps)) return false;
+        p = cross(T, e1);
+        v = dot(r.dir, p) * invDet;
+        if ((v < 0 && std::fabs(v) > kTriEps) || (u + v > 1 && std::fabs(u + v - 1) > kTriEps)) return false;
+        t = dot(e2, p) * invDet;
+        if (t < kTriEps) return false;
+        return true;
+    }
+    void interpolateAttributes(float alpha, float beta, float gamma, V3& nrm, float& iu, float& iv) const // Geometry.h:128-134
+    {
+        nrm = vertices[0].normal * alpha + vertices[1].normal * beta + vertices[2].normal * gamma;
+        nrm = normalize(nrm);
+        iu = vertices[0].u * alpha + vertices[1].u * beta + vertices[2].u * gamma;
+        iv = vertices[0].v * alpha + vertices[1].v * beta + vertices[2].v * gamma;
+    }
+    V3 sample(Sampler* s, float& pdf) const                                          // Geometry.h:137-156
+    {
+        float r1 = s->next();
+        float r2 = s->next();
+        float rootr1 = sqrtf(r1);
+        float alpha = 1 - rootr1;
+        float beta = r2 * rootr1;
+        float gamma = 1 - (alpha + beta);
+        V3 p = vertices[0].p * alpha + vertices[1].p * beta + vertices[2].p * gamma;
+        pdf = 1 / area;
+        return p;
+    }
+    V3 gNormal() const { return (n * (dot(vertices[0].normal, n) > 0 ? 1.0f : -1.0f)); } // Geometry.h:158
+};
+
+struct Box {                                                      // AABB, Geometry.h:164-236
+    V3 max, min;
+    Box() { reset(); }
+    void reset() { max = v3(-FLT_MAX, -FLT_MAX, -FLT_MAX); min = v3(FLT_MAX, FLT_MAX, FLT_MAX); }
+    void extend(V3 p) { max = vmax(max, p); min = vmin(min, p); }
+    bool rayAABB(const Ray& r) const                                                 // Geometry.h:213-228
+    {
+        V3 tmin = (min - r.o) * r.invDir;
+        V3 tmax = (max - r.o) * r.invDir;
+        V3 entry = vmin(tmin, tmax);
+        V3 exit = vmax(tmin, tmax);
+        float tentry = std::max(std::max(entry.x, entry.y), entry.z);
+        float texit = std::min(std::min(exit.x, exit.y), exit.z);
+        return !(tentry > texit || texit < 0);
+    }
+    float area() const { V3 s = max - min; return ((s.x * s.y) + (s.y * s.z) + (s.x * s.z)) * 2.0f; } // Geometry.h:231
+};
+
+struct Hit { unsigned ID = 0xFFFFFFFFu; float t = FLT_MAX, alpha = 0, beta = 0, gamma = 0; }; // IntersectionData, Geometry.h:276
+
+struct BVH {                                                      // BVHTree, Geometry.h:290-611
+    struct Node { Box bounds; unsigned start, end, child_l = 0, child_r = 0; Node(unsigned s, unsigned e) : start(s), end(e) {} };
+    const Tri* tris = nullptr; std::vector<Node> nodes; std::vector<unsigned> indices; unsigned depth = 0;
+    static constexpr int kMaxLeaf = 8, kBins = 15, kMaxDepth = 50;                 // Geometry.h:285-288,306
+    const float invBins = 1.0f / (float)kBins;                                     // Geometry.h:307
+
+    float calcCost(float pA, float lA, float rA, unsigned lN, unsigned rN) const   // Geometry.h:309
+    { return 1.0f + 2.0f * (lA * lN + rA * rN) / pA; }
+    float evaluateSplit(unsigned node, unsigned axis, float splitPos) const        // Geometry.h:314-343: one full sweep per candidate plane
+    {
+        Box a, b; unsigned na = 0, nb = 0;
+        for (unsigned i = nodes[node].start; i < nodes[node].end; i++) {
+            const Tri& t = tris[indices[i]];
+            if (comp(t.centre, axis) < splitPos) { a.extend(t.maxP); a.extend(t.minP); na++; }
+            else { b.extend(t.maxP); b.extend(t.minP); nb++; }
+        }
+        return calcCost(nodes[node].bounds.area(), a.area(), b.area(), na, nb);
+    }
+    bool createSplit(unsigned node, unsigned axis, float splitPos)                  // Geometry.h:345-389
+    {
+        unsigned rStart = nodes[node].start;
+        for (unsigned i = nodes[node].start; i < nodes[node].end; i++) {
+            if (comp(tris[indices[i]].centre, axis) > splitPos) { std::swap(indices[i], indices[rStart]); rStart++; }
+        }
+        if (rStart == nodes[node].start || rStart == nodes[node].end) return false;
+        Node l(nodes[node].start, rStart), r(rStart, nodes[node].end);
+        for (unsigned i = l.start; i < l.end; i++) { l.bounds.extend(tris[indices[i]].maxP); l.bounds.extend(tris[indices[i]].minP); }
+        for (unsigned i = r.start; i < r.end; i++) { r.bounds.extend(tris[indices[i]].maxP); r.bounds.extend(tris[indices[i]].minP); }
+        nodes.push_back(l); nodes.push_back(r);
+        nodes[node].child_l = (unsigned)nodes.size() - 2;
+        nodes[node].child_r = (unsigned)nodes.size() - 1;
+        return true;
+    }
+    bool splitNode(unsigned node)                                                   // Geometry.h:391-430
+    {
+        if (nodes[node].end - nodes[node].start <= (unsigned)kMaxLeaf) return false;
+        unsigned bestAxis = 0; float bestPos = 0, bestCost = FLT_MAX;
+        for (int axis = 0; axis < 3; axis++) {
+            float b0 = comp(nodes[node].bounds.min, axis), b1 = comp(nodes[node].bounds.max, axis);
+            for (int i = 0; i < kBins; i++) {
+                float splitT = (i + 1) * invBins;
+                float pos = b0 + (b1 - b0) * splitT;
+                float cost = evaluateSplit(node, axis, pos);
+                if (cost < bestCost) { bestCost = cost; bestPos = pos; bestAxis = axis; }
+            }
+        }
+        return createSplit(node, bestAxis, bestPos);
+    }
+    unsigned split(unsigned node, int d = 0)                                        // Geometry.h:432-449
+    {
+        if (d >= kMaxDepth) return d;
+        if (!splitNode(node)) return d;
+        d++;
+        unsigned cl = nodes[node].child_l, cr = nodes[node].child_r;
+        unsigned d1 = split(cl, d);
+        unsigned d2 = split(cr, d);
+        return std::max(d1, d2);
+    }
+    void build(const std::vector<Tri>& in, const Box& bounds)                       // Geometry.h:458-504
+    {
+        tris = in.data(); nodes.clear(); indices.resize(in.size());
+        for (unsigned i = 0; i < in.size(); i++) indices[i] = i;
+        nodes.emplace_back(0u, (unsigned)in.size());
+        nodes[0].bounds = bounds;
+        nodes.reserve(in.size() / 2 + 16);
+        depth = split(0);
+    }
+    bool isLeaf(const Node& n) const { return n.child_l == 0 && n.child_r == 0; }  // Geometry.h:523
+    void traverse(const Ray& ray, Hit& hit) const                                   // Geometry.h:506-555
+    {
+        if (nodes.empty() || !nodes[0].bounds.rayAABB(ray)) return;
+        std::vector<unsigned> stack; stack.reserve(64); stack.push_back(0);
+        while (!stack.empty()) {
+            const Node& node = nodes[stack.back()]; stack.pop_back();
+            if (isLeaf(node)) {
+                for (unsigned i = node.start; i < node.end; i++) {
+                    float t, u, v; unsigned index = indices[i];
+                    if (tris[index].rayIntersect(ray, t, u, v)) {
+                        if (t < hit.t) { hit.t = t; hit.ID = index; hit.alpha = u; hit.beta = v; hit.gamma = 1.0f - (u + v); }
+                    }
+                }
+            } else {
+                if (nodes[node.child_l].bounds.rayAABB(ray)) stack.push_back(node.child_l);
+                if (nodes[node.child_r].bounds.rayAABB(ray)) stack.push_back(node.child_r);
+            }
+        }
+    }
+    Hit traverse(const Ray& ray) const { Hit h; traverse(ray, h); return h; }      // Geometry.h:557-566
+    bool traverseVisible(const Ray& ray, float maxT) const                          // Geometry.h:568-610
+    {
+        // a segment whose ray misses the root box is reported NOT visible (Geometry.h:571-572)
+        if (nodes.empty() || !nodes[0].bounds.rayAABB(ray)) return false;
+        std::vector<unsigned> stack; stack.reserve(64); stack.push_back(0);
+        while (!stack.empty()) {
+            const Node& node = nodes[stack.back()]; stack.pop_back();
+            if (isLeaf(node)) {
+                for (unsigned i = node.start; i < node.end; i++) {
+                    float t, u, v;
+                    if (tris[indices[i]].rayIntersect(ray, t, u, v)) if (t <= maxT) return false;
+                }
+            } else {
+                if (nodes[node.child_l].bounds.rayAABB(ray)) stack.push_back(node.child_l);
+                if (nodes[node.child_r].bounds.rayAABB(ray)) stack.push_back(node.child_r);
+            }
+        }
+        return true;
+    }
+};
+
+} // namespace orc

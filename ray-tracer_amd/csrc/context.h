@@ -1,0 +1,56 @@
+// context.h — the renderer context behind the opaque rtx_ctx handle.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "device_scene.h"
+#include "scene_host.h"
+
+namespace rtx {
+
+constexpr int kBlock = 256;        // threads per workgroup (4 waves)
+constexpr int kLdsStack = 12;      // traversal-stack entries per lane kept in LDS
+constexpr int kMaxGridBlocks = 2048;   // 256 CUs x 8 resident workgroups
+
+// Device buffer that frees itself.
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    hipError_t ensure(size_t n) { if (n <= bytes) return hipSuccess; release(); hipError_t e = hipMalloc(&p, n); if (e == hipSuccess) bytes = n; return e; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct WavefrontBuffers;   // path-tracing state (wavefront.h)
+
+} // namespace rtx
+
+struct rtx_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    bool have_scene = false, have_camera = false;
+    rtx::HostScene host;
+    rtx::DeviceScene dscene{};
+    rtx::CameraDev dcam{};
+    rtx_camera cam{};
+    rtx_settings settings{};
+
+    rtx::DevBuf b_nodes4, b_nodes2, b_tris, b_shade, b_materials, b_texels, b_lights, b_env_texels, b_env_rows, b_env_cols;
+    rtx::DevBuf b_spill;           // global part of the traversal stacks
+    uint32_t spill_entries = 0;    // entries per lane in b_spill
+    rtx::DevBuf b_io_a, b_io_b;    // staging for the host-pointer entry points
+    rtx::DevBuf b_counters;
+
+    // progressive state
+    rtx::DevBuf b_film, b_tile_samples;
+    int spp = 0;
+    uint32_t tiles_x = 0, tiles_y = 0;
+    rtx::WavefrontBuffers* wf = nullptr;
+
+    rtx_stats stats{};
+};

@@ -1,0 +1,86 @@
+// device_scene.h — the scene as the HIP kernels see it (plain pointers into HBM).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rtx.h"
+
+namespace rtx {
+
+// One triangle in leaf order, 48 bytes = three 16-byte loads:
+//   q0 = e1.xyz, original triangle index (bit pattern)
+//   q1 = e2.xyz, 0
+//   q2 = v2.xyz, 0
+struct TriIsect { float4 q0, q1, q2; };
+
+// Shading attributes per ORIGINAL triangle index, 96 bytes (Triangle members read by
+// Scene::calculateShadingData, RTBase/Scene.h:183-213, and by the lights).
+struct TriShade {
+    float n0[3], n1[3], n2[3];   // vertex normals
+    float uv0[2], uv1[2], uv2[2];
+    float gn[3];                 // Triangle::n, Geometry.h:85 (unflipped)
+    float gsign;                 // sign applied by Triangle::gNormal, Geometry.h:158-161
+    uint32_t material;
+    float area;                  // Geometry.h:87
+    float pad[3];
+};
+static_assert(sizeof(TriShade) == 96, "TriShade layout");
+
+// Material record after the constructors of RTBase/Materials.h have run.
+struct MaterialDev {
+    int32_t type;
+    int32_t tex_offset;          // first texel (in RGB triples) inside DeviceScene::texels
+    int32_t tex_w, tex_h;
+    float emission[3];
+    int32_t is_light;            // BSDF::isLight, Materials.h:123
+    float eta[3];
+    float alpha;                 // 1.62142*sqrt(roughness), Materials.h:248,582
+    float k[3];
+    float eta_d;                 // extIOR/intIOR, Materials.h:368,584
+    float inv_eta;               // Materials.h:369
+    float phong_e;               // Materials.h:585
+    float pad[2];
+};
+
+// One emitter of Scene::lights (RTBase/Scene.h:83): kind 0 = area triangle, 1 = constant
+// background, 2 = environment map.
+struct LightDev {
+    int32_t kind;
+    uint32_t tri;                // original triangle index (area)
+    float v0[3], v1[3], v2[3];   // area light vertices (Triangle::sample, Geometry.h:137-156)
+    float gnormal[3];            // Triangle::gNormal()
+    float area;
+    float emission[3];
+};
+
+struct CameraDev {
+    float proj[16], inv_proj[16], camera[16], camera_to_view[16];
+    float origin[3], view_dir[3];
+    float afilm, width, height;
+    int32_t w, h;
+};
+
+struct DeviceScene {
+    const float4* nodes4;        // Node4 array as float4[8] per node
+    const float4* nodes2;        // Node2Dev array as float4[2] per node
+    const TriIsect* tris;        // leaf order
+    const TriShade* shade;       // original order
+    const MaterialDev* materials;
+    const float* texels;         // all textures, RGB triples
+    const LightDev* lights;
+    uint32_t n_lights;
+    uint32_t n_tris;
+    float root_min[3], root_max[3];
+    // background / environment (RTBase/Lights.h:86-135, 307-413)
+    int32_t bg_kind;             // 1 constant, 2 environment map
+    float bg_emission[3];
+    int32_t env_w, env_h;
+    const float* env_texels;     // RGB triples
+    const float* env_cdf_rows;   // [h]   TabulatedDistribution::cdfRows
+    const float* env_cdf_cols;   // [h*w] TabulatedDistribution::cdfCols
+    float env_inv_w, env_inv_h;
+    float scene_centre[3], scene_radius;   // SceneBounds, SceneLoader.h:387-388
+};
+
+} // namespace rtx

@@ -1,0 +1,410 @@
+// rtx_api.hip — implementation of the C ABI declared in include/rtx.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "context.h"
+#include "trace_kernels.h"
+#include "wavefront.h"
+
+using namespace rtx;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(RTX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+#define CTX_TRY(ctx) do { if (!(ctx)) return fail(RTX_ERR_INVALID, "null context"); HIP_TRY(hipSetDevice((ctx)->device)); } while (0)
+
+template <class T>
+int upload(DevBuf& b, const std::vector<T>& v, hipStream_t s)
+{
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    HIP_TRY(b.ensure(bytes));
+    if (!v.empty()) HIP_TRY(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return RTX_OK;
+}
+
+int grid_for(size_t n) { return (int)std::min<size_t>((n + kBlock - 1) / kBlock, kMaxGridBlocks); }
+
+int ensure_spill(rtx_ctx* c)
+{
+    size_t bytes = std::max<size_t>((size_t)c->spill_entries * kMaxGridBlocks * kBlock * sizeof(uint2), 16);
+    HIP_TRY(c->b_spill.ensure(bytes));
+    return RTX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* rtx_last_error(void) { return g_err; }
+
+int rtx_create(rtx_ctx** out, int device)
+{
+    if (!out) return fail(RTX_ERR_INVALID, "out is null");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(RTX_ERR_INVALID, "device %d out of range (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    rtx_ctx* c = new (std::nothrow) rtx_ctx;
+    if (!c) return fail(RTX_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    HIP_TRY(c->b_counters.ensure(64));
+    // RayTracer's defaults, RTBase/Settings.h:40-61
+    rtx_settings& s = c->settings;
+    s.algorithm = RTX_AL_PATH_TRACE; s.draw_mode = RTX_DM_ALGORITHM; s.filter = RTX_FT_BOX;
+    s.use_mis = 0; s.can_hit_light = 0; s.adaptive_sampling = 0;
+    s.max_bounces = 5; s.init_spp = 10; s.total_spp = 8192; s.vpl_rays_per_tile = 1; s.num_threads = 3;
+    s.seed = 1; s.shard_mode = 0; s.shard_rank = 0; s.shard_world = 1;
+    *out = c;
+    return RTX_OK;
+}
+
+void rtx_destroy(rtx_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    wavefront_release(c);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int rtx_set_stream(rtx_ctx* c, void* s)
+{
+    CTX_TRY(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return RTX_OK;
+}
+
+int rtx_synchronize(rtx_ctx* c) { CTX_TRY(c); HIP_TRY(hipStreamSynchronize(c->stream)); return RTX_OK; }
+
+int rtx_upload_scene(rtx_ctx* c, const rtx_scene_desc* d)
+{
+    CTX_TRY(c);
+    if (!d) return fail(RTX_ERR_INVALID, "scene is null");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_scene = false;
+    std::string err = prepare_scene(*d, c->host);
+    if (!err.empty()) return fail(RTX_ERR_INVALID, "scene rejected: %s", err.c_str());
+    const HostScene& h = c->host;
+    hipStream_t s = c->stream;
+    int rc;
+    if ((rc = upload(c->b_nodes4, h.bvh4.nodes, s))) return rc;
+    if ((rc = upload(c->b_nodes2, h.bvh4.nodes2, s))) return rc;
+    if ((rc = upload(c->b_tris, h.tris, s))) return rc;
+    if ((rc = upload(c->b_shade, h.shade, s))) return rc;
+    if ((rc = upload(c->b_materials, h.materials, s))) return rc;
+    if ((rc = upload(c->b_texels, h.texels, s))) return rc;
+    if ((rc = upload(c->b_lights, h.lights, s))) return rc;
+    if ((rc = upload(c->b_env_texels, h.env_texels, s))) return rc;
+    if ((rc = upload(c->b_env_rows, h.env_cdf_rows, s))) return rc;
+    if ((rc = upload(c->b_env_cols, h.env_cdf_cols, s))) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+
+    DeviceScene& ds = c->dscene;
+    ds.nodes4 = c->b_nodes4.as<float4>(); ds.nodes2 = c->b_nodes2.as<float4>(); ds.tris = c->b_tris.as<TriIsect>();
+    ds.shade = c->b_shade.as<TriShade>(); ds.materials = c->b_materials.as<MaterialDev>(); ds.texels = c->b_texels.as<float>();
+    ds.lights = c->b_lights.as<LightDev>(); ds.n_lights = (uint32_t)h.lights.size(); ds.n_tris = (uint32_t)h.tris.size();
+    for (int a = 0; a < 3; a++) { ds.root_min[a] = h.bvh4.root_min[a]; ds.root_max[a] = h.bvh4.root_max[a]; ds.bg_emission[a] = h.bg_emission[a]; ds.scene_centre[a] = h.scene_centre[a]; }
+    ds.bg_kind = h.bg_kind; ds.env_w = h.env_w; ds.env_h = h.env_h;
+    ds.env_texels = c->b_env_texels.as<float>(); ds.env_cdf_rows = c->b_env_rows.as<float>(); ds.env_cdf_cols = c->b_env_cols.as<float>();
+    ds.env_inv_w = h.env_w ? 1.0f / (float)h.env_w : 0.f; ds.env_inv_h = h.env_h ? 1.0f / (float)h.env_h : 0.f;
+    ds.scene_radius = h.scene_radius;
+
+    // traversal stack: at most three pushes per wide level, or one pending node per binary
+    // level on the exact path; entries beyond the LDS part go to global memory
+    uint32_t need = std::max(3u * h.bvh4.depth + 2u, h.bvh2.depth + 3u);
+    c->spill_entries = need > (uint32_t)kLdsStack ? need - kLdsStack : 0;
+    if ((rc = ensure_spill(c))) return rc;
+
+    c->stats.bvh2_nodes = (uint32_t)h.bvh2.nodes.size(); c->stats.bvh2_depth = h.bvh2.depth;
+    c->stats.bvh4_nodes = (uint32_t)h.bvh4.nodes.size(); c->stats.bvh4_depth = h.bvh4.depth;
+    c->stats.n_lights = ds.n_lights; c->stats.build_ms = h.build_ms;
+    c->have_scene = true;
+    return RTX_OK;
+}
+
+int rtx_camera_look_at(rtx_camera* out, const float from[3], const float to[3], const float up[3],
+                       float fov_deg, int width, int height, int flip_x)
+{
+    if (!out || !from || !to || !up) return fail(RTX_ERR_INVALID, "null argument");
+    if (width < 1 || height < 1) return fail(RTX_ERR_INVALID, "bad film size %dx%d", width, height);
+    camera_look_at(*out, from, to, up, fov_deg, width, height, flip_x);
+    return RTX_OK;
+}
+
+int rtx_set_camera(rtx_ctx* c, const rtx_camera* cam)
+{
+    CTX_TRY(c);
+    if (!cam) return fail(RTX_ERR_INVALID, "camera is null");
+    if (cam->width < 1 || cam->height < 1 || (uint64_t)cam->width * cam->height > (1ull << 28)) return fail(RTX_ERR_INVALID, "bad film size %dx%d", cam->width, cam->height);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    bool resized = !c->have_camera || cam->width != c->cam.width || cam->height != c->cam.height;
+    c->cam = *cam;
+    CameraDev& d = c->dcam;
+    std::memcpy(d.proj, cam->proj, 64); std::memcpy(d.inv_proj, cam->inv_proj, 64);
+    std::memcpy(d.camera, cam->camera, 64); std::memcpy(d.camera_to_view, cam->camera_to_view, 64);
+    for (int a = 0; a < 3; a++) { d.origin[a] = cam->origin[a]; d.view_dir[a] = cam->view_dir[a]; }
+    d.afilm = cam->afilm; d.width = (float)cam->width; d.height = (float)cam->height; d.w = cam->width; d.h = cam->height;
+    c->have_camera = true;
+    if (resized) {
+        // Film::init, RTBase/Imaging.h:388-395; tile grid, RTBase/Renderer.h:107-112
+        c->tiles_x = (cam->width + 15) / 16; c->tiles_y = (cam->height + 15) / 16;
+        HIP_TRY(c->b_film.ensure((size_t)cam->width * cam->height * 3 * sizeof(float)));
+        HIP_TRY(c->b_tile_samples.ensure((size_t)c->tiles_x * c->tiles_y * sizeof(uint32_t)));
+        int rc = wavefront_resize(c); if (rc) return fail(rc, "wavefront buffers: allocation failed");
+        return rtx_clear(c);
+    }
+    return RTX_OK;
+}
+
+int rtx_set_settings(rtx_ctx* c, const rtx_settings* s)
+{
+    CTX_TRY(c);
+    if (!s) return fail(RTX_ERR_INVALID, "settings is null");
+    if (s->algorithm < 0 || s->algorithm > 2 || s->draw_mode < 0 || s->draw_mode > 3 || s->filter < 0 || s->filter > 2)
+        return fail(RTX_ERR_INVALID, "enum out of range");
+    if (s->shard_mode < 0 || s->shard_mode > 2 || s->shard_world < 1 || s->shard_rank < 0 || s->shard_rank >= s->shard_world)
+        return fail(RTX_ERR_INVALID, "bad shard (mode %d rank %d world %d)", s->shard_mode, s->shard_rank, s->shard_world);
+    if (s->max_bounces > 64) return fail(RTX_ERR_INVALID, "max_bounces %u too large", s->max_bounces);
+    c->settings = *s;
+    // RayTracer::init, RTBase/Renderer.h:81-84
+    c->settings.adaptive_sampling = s->adaptive_sampling && s->algorithm == RTX_AL_PATH_TRACE;
+    if (!c->settings.adaptive_sampling) c->settings.init_spp = s->total_spp;
+    return RTX_OK;
+}
+
+int rtx_clear(rtx_ctx* c)
+{
+    CTX_TRY(c);
+    if (!c->have_camera) return fail(RTX_ERR_STATE, "no camera set");
+    HIP_TRY(hipMemsetAsync(c->b_film.p, 0, (size_t)c->cam.width * c->cam.height * 3 * sizeof(float), c->stream));
+    c->spp = 0;
+    return RTX_OK;
+}
+
+int rtx_get_spp(rtx_ctx* c, int* spp) { if (!c || !spp) return fail(RTX_ERR_INVALID, "null argument"); *spp = c->spp; return RTX_OK; }
+int rtx_set_spp(rtx_ctx* c, int spp) { if (!c || spp < 0) return fail(RTX_ERR_INVALID, "bad argument"); c->spp = spp; return RTX_OK; }
+
+int rtx_render_passes(rtx_ctx* c, int n)
+{
+    CTX_TRY(c);
+    if (!c->have_scene || !c->have_camera) return fail(RTX_ERR_STATE, "scene and camera must be set before rendering");
+    if (n < 0) return fail(RTX_ERR_INVALID, "negative pass count");
+    for (int i = 0; i < n; i++) {
+        int rc = wavefront_render_pass(c);
+        if (rc) return fail(rc, "render pass failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RTX_OK;
+}
+
+int rtx_film_read(rtx_ctx* c, float* rgb, int* spp, uint32_t* tiles)
+{
+    CTX_TRY(c);
+    if (!c->have_camera) return fail(RTX_ERR_STATE, "no camera set");
+    if (rgb) HIP_TRY(hipMemcpyAsync(rgb, c->b_film.p, (size_t)c->cam.width * c->cam.height * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (tiles) HIP_TRY(hipMemcpyAsync(tiles, c->b_tile_samples.p, (size_t)c->tiles_x * c->tiles_y * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (spp) *spp = c->spp;
+    return RTX_OK;
+}
+
+int rtx_film_device(rtx_ctx* c, void** p, size_t* n)
+{
+    if (!c || !p) return fail(RTX_ERR_INVALID, "null argument");
+    if (!c->have_camera) return fail(RTX_ERR_STATE, "no camera set");
+    *p = c->b_film.p; if (n) *n = (size_t)c->cam.width * c->cam.height * 3;
+    return RTX_OK;
+}
+
+int rtx_tile_samples_device(rtx_ctx* c, void** p, size_t* n)
+{
+    if (!c || !p) return fail(RTX_ERR_INVALID, "null argument");
+    if (!c->have_camera) return fail(RTX_ERR_STATE, "no camera set");
+    *p = c->b_tile_samples.p; if (n) *n = (size_t)c->tiles_x * c->tiles_y;
+    return RTX_OK;
+}
+
+int rtx_update_tile_samples(rtx_ctx* c)
+{
+    CTX_TRY(c);
+    if (!c->have_camera) return fail(RTX_ERR_STATE, "no camera set");
+    int rc = wavefront_tile_samples(c);
+    if (rc) return fail(rc, "tile statistics kernel failed");
+    return RTX_OK;
+}
+
+// ---- ray queries -------------------------------------------------------------------------
+
+int rtx_trace_closest_device(rtx_ctx* c, const rtx_ray* rays, size_t n, rtx_hit* hits)
+{
+    CTX_TRY(c);
+    if (!c->have_scene) return fail(RTX_ERR_STATE, "no scene uploaded");
+    if (n == 0) return RTX_OK;
+    if (!rays || !hits) return fail(RTX_ERR_INVALID, "null buffer");
+    if (n > 0xFFFFFFFFull) return fail(RTX_ERR_INVALID, "too many rays in one call");
+    hipLaunchKernelGGL(k_closest<false>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, c->dscene, rays, (const uint32_t*)nullptr,
+                       (uint32_t)n, hits, c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), (unsigned long long*)nullptr);
+    HIP_TRY(hipGetLastError());
+    c->stats.closest_rays += n;
+    return RTX_OK;
+}
+
+int rtx_trace_closest(rtx_ctx* c, const rtx_ray* rays, size_t n, rtx_hit* hits)
+{
+    CTX_TRY(c);
+    if (n == 0) return RTX_OK;
+    if (!rays || !hits) return fail(RTX_ERR_INVALID, "null buffer");
+    HIP_TRY(c->b_io_a.ensure(n * sizeof(rtx_ray)));
+    HIP_TRY(c->b_io_b.ensure(n * sizeof(rtx_hit)));
+    HIP_TRY(hipMemcpyAsync(c->b_io_a.p, rays, n * sizeof(rtx_ray), hipMemcpyHostToDevice, c->stream));
+    int rc = rtx_trace_closest_device(c, c->b_io_a.as<rtx_ray>(), n, c->b_io_b.as<rtx_hit>());
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(hits, c->b_io_b.p, n * sizeof(rtx_hit), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RTX_OK;
+}
+
+int rtx_trace_visible_device(rtx_ctx* c, const float* p1p2, size_t n, uint8_t* vis)
+{
+    CTX_TRY(c);
+    if (!c->have_scene) return fail(RTX_ERR_STATE, "no scene uploaded");
+    if (n == 0) return RTX_OK;
+    if (!p1p2 || !vis) return fail(RTX_ERR_INVALID, "null buffer");
+    if (n > 0xFFFFFFFFull) return fail(RTX_ERR_INVALID, "too many segments in one call");
+    hipLaunchKernelGGL(k_visible, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, c->dscene, p1p2, (uint32_t)n, vis,
+                       c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock));
+    HIP_TRY(hipGetLastError());
+    c->stats.shadow_rays += n;
+    return RTX_OK;
+}
+
+int rtx_trace_visible(rtx_ctx* c, const float* p1p2, size_t n, uint8_t* vis)
+{
+    CTX_TRY(c);
+    if (n == 0) return RTX_OK;
+    if (!p1p2 || !vis) return fail(RTX_ERR_INVALID, "null buffer");
+    HIP_TRY(c->b_io_a.ensure(n * 6 * sizeof(float)));
+    HIP_TRY(c->b_io_b.ensure(n));
+    HIP_TRY(hipMemcpyAsync(c->b_io_a.p, p1p2, n * 6 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    int rc = rtx_trace_visible_device(c, c->b_io_a.as<float>(), n, c->b_io_b.as<uint8_t>());
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(vis, c->b_io_b.p, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RTX_OK;
+}
+
+int rtx_generate_primary_rays_device(rtx_ctx* c, rtx_ray* rays, uint32_t* pixel, size_t cap)
+{
+    CTX_TRY(c);
+    if (!c->have_camera) return fail(RTX_ERR_STATE, "no camera set");
+    size_t n = (size_t)c->cam.width * c->cam.height;
+    if (!rays) return fail(RTX_ERR_INVALID, "null buffer");
+    if (cap < n) return fail(RTX_ERR_INVALID, "ray buffer holds %zu rays, film needs %zu", cap, n);
+    hipLaunchKernelGGL(k_primary_rays, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->dcam, rays, pixel);
+    HIP_TRY(hipGetLastError());
+    return RTX_OK;
+}
+
+int rtx_count_closest_work(rtx_ctx* c, const rtx_ray* rays, size_t n, uint64_t* nodes, uint64_t* tris)
+{
+    CTX_TRY(c);
+    if (!c->have_scene) return fail(RTX_ERR_STATE, "no scene uploaded");
+    if (!rays || !nodes || !tris || n == 0 || n > 0xFFFFFFFFull) return fail(RTX_ERR_INVALID, "bad argument");
+    HIP_TRY(c->b_io_b.ensure(n * sizeof(rtx_hit)));
+    HIP_TRY(hipMemsetAsync(c->b_counters.p, 0, 16, c->stream));
+    hipLaunchKernelGGL(k_closest<true>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, c->dscene, rays, (const uint32_t*)nullptr,
+                       (uint32_t)n, c->b_io_b.as<rtx_hit>(), c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock),
+                       c->b_counters.as<unsigned long long>());
+    HIP_TRY(hipGetLastError());
+    unsigned long long h[2];
+    HIP_TRY(hipMemcpyAsync(h, c->b_counters.p, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *nodes = h[0]; *tris = h[1];
+    return RTX_OK;
+}
+
+// ---- introspection -----------------------------------------------------------------------
+
+int rtx_get_bvh(rtx_ctx* c, uint32_t* n_nodes, float* bounds, uint32_t* topo, uint32_t* indices)
+{
+    if (!c) return fail(RTX_ERR_INVALID, "null context");
+    if (!c->have_scene) return fail(RTX_ERR_STATE, "no scene uploaded");
+    const Bvh2& b = c->host.bvh2;
+    if (n_nodes) *n_nodes = (uint32_t)b.nodes.size();
+    for (size_t i = 0; i < b.nodes.size(); i++) {
+        const Bvh2Node& n = b.nodes[i];
+        if (bounds) { for (int a = 0; a < 3; a++) { bounds[i * 6 + a] = n.bmin[a]; bounds[i * 6 + 3 + a] = n.bmax[a]; } }
+        if (topo) { topo[i * 4] = n.start; topo[i * 4 + 1] = n.end; topo[i * 4 + 2] = n.child_l; topo[i * 4 + 3] = n.child_r; }
+    }
+    if (indices) std::memcpy(indices, b.indices.data(), b.indices.size() * sizeof(uint32_t));
+    return RTX_OK;
+}
+
+struct rtx_host_bvh { HostScene hs; };
+
+int rtx_host_bvh_build(const rtx_scene_desc* d, rtx_host_bvh** out)
+{
+    if (!d || !out) return fail(RTX_ERR_INVALID, "null argument");
+    rtx_host_bvh* h = new (std::nothrow) rtx_host_bvh;
+    if (!h) return fail(RTX_ERR_NOMEM, "out of host memory");
+    std::string err = prepare_scene(*d, h->hs);
+    if (!err.empty()) { delete h; return fail(RTX_ERR_INVALID, "scene rejected: %s", err.c_str()); }
+    *out = h;
+    return RTX_OK;
+}
+
+int rtx_host_bvh_get(const rtx_host_bvh* h, uint32_t* n_nodes, uint32_t* depth, float* bounds, uint32_t* topo,
+                     uint32_t* indices, uint32_t* wide_nodes, uint32_t* wide_depth)
+{
+    if (!h) return fail(RTX_ERR_INVALID, "null handle");
+    const Bvh2& b = h->hs.bvh2;
+    if (n_nodes) *n_nodes = (uint32_t)b.nodes.size();
+    if (depth) *depth = b.depth;
+    if (wide_nodes) *wide_nodes = (uint32_t)h->hs.bvh4.nodes.size();
+    if (wide_depth) *wide_depth = h->hs.bvh4.depth;
+    for (size_t i = 0; i < b.nodes.size(); i++) {
+        const Bvh2Node& n = b.nodes[i];
+        if (bounds) { for (int a = 0; a < 3; a++) { bounds[i * 6 + a] = n.bmin[a]; bounds[i * 6 + 3 + a] = n.bmax[a]; } }
+        if (topo) { topo[i * 4] = n.start; topo[i * 4 + 1] = n.end; topo[i * 4 + 2] = n.child_l; topo[i * 4 + 3] = n.child_r; }
+    }
+    if (indices) std::memcpy(indices, b.indices.data(), b.indices.size() * sizeof(uint32_t));
+    return RTX_OK;
+}
+
+void rtx_host_bvh_free(rtx_host_bvh* h) { delete h; }
+
+int rtx_get_stats(rtx_ctx* c, rtx_stats* out) { if (!c || !out) return fail(RTX_ERR_INVALID, "null argument"); *out = c->stats; return RTX_OK; }
+int rtx_reset_stats(rtx_ctx* c) { if (!c) return fail(RTX_ERR_INVALID, "null context"); c->stats.closest_rays = c->stats.shadow_rays = c->stats.samples = 0; return RTX_OK; }
+
+int rtx_timer_begin(rtx_ctx* c) { CTX_TRY(c); HIP_TRY(hipEventRecord(c->ev0, c->stream)); return RTX_OK; }
+int rtx_timer_end(rtx_ctx* c, float* ms)
+{
+    CTX_TRY(c);
+    if (!ms) return fail(RTX_ERR_INVALID, "null argument");
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return RTX_OK;
+}
+
+} // extern "C"

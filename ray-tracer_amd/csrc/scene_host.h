@@ -1,0 +1,38 @@
+// scene_host.h — host-side preparation of the device scene (everything Scene::init,
+// Scene::build, the material constructors and TabulatedDistribution::init compute once).
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "bvh_host.h"
+#include "device_scene.h"
+
+namespace rtx {
+
+struct HostScene {
+    Bvh2 bvh2;
+    Bvh4 bvh4;
+    std::vector<TriIsect> tris;        // leaf order
+    std::vector<TriShade> shade;       // original order
+    std::vector<MaterialDev> materials;
+    std::vector<float> texels;         // all textures back to back, RGB
+    std::vector<LightDev> lights;      // Scene::lights order: background first (if it has power), then emissive triangles by index
+    int bg_kind = 1;
+    float bg_emission[3] = {0, 0, 0};
+    int env_w = 0, env_h = 0;
+    std::vector<float> env_texels, env_cdf_rows, env_cdf_cols;
+    float env_avg_lum = 0;
+    float scene_centre[3] = {0, 0, 0}, scene_radius = 0;
+    float build_ms = 0;
+};
+
+// Returns an empty string on success, otherwise the reason the description was rejected.
+std::string prepare_scene(const rtx_scene_desc& d, HostScene& out);
+
+// Camera::init + Camera::updateView (RTBase/Scene.h:22-41) after loadScene's matrix set-up
+// (RTBase/SceneLoader.h:342-360).
+void camera_look_at(rtx_camera& out, const float from[3], const float to[3], const float up[3],
+                    float fov_deg, int width, int height, int flip_x);
+
+} // namespace rtx

@@ -1,0 +1,151 @@
+"""GPU parity of the ray-query entry points (rtx_trace_closest / rtx_trace_visible) against
+the CPU oracle: hit id, t and barycentrics must agree BIT FOR BIT, visibility exactly.
+
+Ray sets follow what a BVH traversal can get wrong: coherent primary rays, incoherent
+rays, rays with zero direction components (the reference's slab test produces NaNs there,
+RTBase/Geometry.h:213-228), rays starting on surfaces, coplanar duplicate triangles
+(equal-t ties, RTBase/Geometry.h:535) and leaves that cannot be split.
+"""
+import numpy as np
+import pytest
+
+from conftest import pixel_centres
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_rays(pkg, n, seed, extent=1.2):
+    rs = np.random.RandomState(seed)
+    rays = np.empty(n, pkg.RAY_DTYPE)
+    rays["o"] = rs.uniform(-extent, extent, (n, 3)).astype(np.float32)
+    d = rs.normal(size=(n, 3)).astype(np.float32)
+    rays["d"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    return rays
+
+
+def _axis_rays(pkg, n, seed, extent=1.2, snap=None):
+    """Directions with one or two exactly-zero components; origins optionally snapped to
+    coordinates that occur in the scene (box faces)."""
+    rs = np.random.RandomState(seed)
+    rays = np.empty(n, pkg.RAY_DTYPE)
+    o = rs.uniform(-extent, extent, (n, 3)).astype(np.float32)
+    if snap is not None:
+        pick = rs.randint(0, len(snap), (n, 3))
+        mask = rs.rand(n, 3) < 0.5
+        o = np.where(mask, snap[pick].astype(np.float32), o)
+    d = rs.normal(size=(n, 3)).astype(np.float32)
+    zero = rs.rand(n, 3) < 0.45
+    zero[zero.all(1)] = [True, False, True]
+    d[zero] = 0.0
+    neg = rs.rand(n, 3) < 0.5
+    d = np.where(zero & neg, np.float32(-0.0), d)
+    nz = np.linalg.norm(d, axis=1, keepdims=True)
+    nz[nz == 0] = 1
+    rays["o"], rays["d"] = o, (d / nz).astype(np.float32)
+    return rays
+
+
+def _assert_hits_equal(got, want):
+    assert np.array_equal(got["id"], want["id"]), f"{(got['id'] != want['id']).sum()} hit ids differ"
+    for f in ("t", "alpha", "beta", "gamma"):
+        hit = want["id"] != 0xFFFFFFFF
+        assert np.array_equal(got[f][hit].view(np.uint32), want[f][hit].view(np.uint32)), f"{f} differs"
+    assert np.all(got["t"][~hit] == np.finfo(np.float32).max)
+
+
+def _check_scene(pkg, lib, core, orc, scene, cam_kw, w=160, h=120, n_rand=40000, snap=None):
+    core.upload_scene(scene)
+    cam = pkg.look_at(lib, width=w, height=h, **cam_kw)
+    core.set_camera(cam)
+    osc = orc.scene(scene)
+    osc.set_camera(cam)
+    rays = np.concatenate([osc.generate_rays(pixel_centres(w, h)), _rand_rays(pkg, n_rand, 1),
+                           _axis_rays(pkg, n_rand // 2, 2, snap=snap)])
+    want = osc.trace_closest(rays)
+    got = core.trace_closest(rays)
+    _assert_hits_equal(got, want)
+    # secondary rays leaving the hit points (origins on surfaces)
+    hit = want["id"] != 0xFFFFFFFF
+    o2 = rays["o"][hit] + rays["d"][hit] * want["t"][hit][:, None]
+    sec = _rand_rays(pkg, int(hit.sum()), 3)
+    sec["o"] = o2.astype(np.float32)
+    _assert_hits_equal(core.trace_closest(sec), osc.trace_closest(sec))
+    # visibility: hit point -> random point, hit point -> hit point
+    rs = np.random.RandomState(4)
+    p2 = np.concatenate([rs.uniform(-1.5, 1.5, (len(o2) // 2, 3)).astype(np.float32), np.roll(o2, 7, axis=0)[: len(o2) - len(o2) // 2]])
+    seg = np.concatenate([o2.astype(np.float32), p2.astype(np.float32)], 1)
+    assert np.array_equal(core.trace_visible(seg), osc.trace_visible(seg))
+    osc.close()
+    return int(hit.sum())
+
+
+def test_closest_and_visible_soup(pkg, lib, core, orc, scenes):
+    n = _check_scene(pkg, lib, core, orc, scenes.soup(100_000, seed=11), dict(frm=(0, 0, 3.5), to=(0, 0, 0), up=(0, 1, 0), fov=45.0))
+    assert n > 10000
+
+
+def test_closest_and_visible_cornell_axis_aligned(pkg, lib, core, orc, scenes):
+    snap = np.array([-1, 1, 0.999, -0.7, -0.1, 0.2, 0.0, 0.1, 0.7, -0.4, 0.6, -0.25, 0.25, -0.6], np.float32)
+    _check_scene(pkg, lib, core, orc, scenes.cornell_box("mixed"), scenes.cornell_camera(), snap=snap)
+
+
+def test_closest_mixed_scene_smooth_meshes(pkg, lib, core, orc, scenes):
+    _check_scene(pkg, lib, core, orc, scenes.mixed_scene(48, (64, 32)), scenes.mixed_camera())
+
+
+def test_ties_and_unsplittable_leaves(pkg, lib, core, orc, scenes):
+    """40 identical copies of a few triangles: every copy returns the same t, the reference
+    keeps the first one it visits; their shared centre makes the node unsplittable, so the
+    leaf holds more triangles than a device leaf slot."""
+    base = scenes.soup(200, seed=5, size=0.2)
+    pos = np.tile(base.positions[:6], (40, 1, 1))
+    extra = scenes.soup(3000, seed=6, size=0.05)
+    P = np.concatenate([pos, extra.positions]); N = np.concatenate([np.tile(base.normals[:6], (40, 1, 1)), extra.normals])
+    U = np.concatenate([np.tile(base.uvs[:6], (40, 1, 1)), extra.uvs])
+    sc = pkg.SceneArrays(P, N, U, np.zeros(len(P), np.uint32), base.materials, base.textures)
+    core.upload_scene(sc)
+    osc = orc.scene(sc)
+    rays = _rand_rays(pkg, 60000, 9)
+    # aim half of the rays at the duplicated triangles
+    tgt = base.positions[:6].mean(1)[np.random.RandomState(1).randint(0, 6, 30000)]
+    d = tgt - rays["o"][:30000]
+    rays["d"][:30000] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    want = osc.trace_closest(rays)
+    assert (want["id"][:30000] < 240).sum() > 5000
+    _assert_hits_equal(core.trace_closest(rays), want)
+    osc.close()
+
+
+def test_empty_and_tiny_inputs(pkg, lib, core, orc, scenes):
+    sc = scenes.soup(3, seed=2, size=0.5)
+    core.upload_scene(sc)
+    osc = orc.scene(sc)
+    assert core.trace_closest(np.empty(0, pkg.RAY_DTYPE)).shape == (0,)
+    rays = _rand_rays(pkg, 1000, 5)
+    _assert_hits_equal(core.trace_closest(rays), osc.trace_closest(rays))
+    assert core.trace_visible(np.empty((0, 6), np.float32)).shape == (0,)
+    osc.close()
+
+
+def test_bvh_matches_oracle_on_device_context(pkg, lib, core, orc, scenes):
+    sc = scenes.soup(30_000, seed=21)
+    core.upload_scene(sc)
+    b, t, i, d = core.bvh()
+    ob, ot, oi, od = orc.scene(sc).bvh()
+    assert d == od and np.array_equal(t, ot) and np.array_equal(i, oi) and np.array_equal(b, ob)
+
+
+def test_full_size_1m_soup_1080p_bit_exact(pkg, lib, core, orc, scenes):
+    """The benchmark configuration itself: 1 M-triangle soup, 1920x1080 pixel-centre rays."""
+    sc = scenes.soup(1_000_000, seed=12345)
+    core.upload_scene(sc)
+    cam = pkg.look_at(lib, (0, 0, 3.5), (0, 0, 0), (0, 1, 0), 45.0, 1920, 1080)
+    core.set_camera(cam)
+    osc = orc.scene(sc)
+    osc.set_camera(cam)
+    rays = osc.generate_rays(pixel_centres(1920, 1080))
+    want = osc.trace_closest(rays, threads=16)
+    got = core.trace_closest(rays)
+    _assert_hits_equal(got, want)
+    assert (want["id"] != 0xFFFFFFFF).sum() > 500_000
+    osc.close()
