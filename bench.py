@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: closest-hit Mrays/s on the 1 M-triangle soup at 1920x1080
+(BASELINE.json configs[1]), plus the 1080p path-trace spp/s of the mixed-material scene as
+extra keys on the same JSON line.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (torch.distributed / RCCL when N > 1). A step is one closest-hit
+launch over one batch of 2,073,600 primary rays that are already resident in HBM (the
+core's own 8x8-tile queue order). Every rank traces its own batch (weak scaling, no
+data-path collective); value = rays of all ranks / max-over-ranks time.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
+NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 128, 48, 24, 20
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--triangles", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pathtrace", action="store_true")
+    ap.add_argument("--pt-spp", type=int, default=16, help="passes of the path-trace side measurement")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    pkg = importlib.import_module("ray-tracer_amd")
+    scenes = importlib.import_module("ray-tracer_amd.scenes")
+    lib = pkg.load_library()
+    core = pkg.Core(local_rank, lib)
+    # enqueue on torch's current stream so torch events / synchronize see the kernels
+    core.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    scene = scenes.soup(args.triangles, seed=12345)
+    core.upload_scene(scene)
+    cam = pkg.look_at(lib, (0, 0, 3.5), (0, 0, 0), (0, 1, 0), 45.0, args.width, args.height)
+    core.set_camera(cam)
+    n = args.width * args.height
+    rays = torch.empty(n * RAY_BYTES, dtype=torch.uint8, device=dev)
+    hits = torch.empty(n * HIT_BYTES, dtype=torch.uint8, device=dev)
+    pixel = torch.empty(n, dtype=torch.int32, device=dev)
+    core.generate_primary_rays_device(rays.data_ptr(), pixel.data_ptr(), n)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        core.trace_closest_device(rays.data_ptr(), n, hits.data_ptr())
+    barrier()
+    t0 = time.perf_counter()
+    core.timer_begin()
+    for _ in range(args.steps):
+        core.trace_closest_device(rays.data_ptr(), n, hits.data_ptr())
+    kernel_ms = core.timer_end() / max(args.steps, 1)     # HIP events on the launch stream
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    mrays = world * n * args.steps / elapsed / 1e6
+
+    # algorithmic traffic of the layout for these rays (instrumented pass, untimed)
+    nodes, tris = core.count_closest_work(rays.data_ptr(), n)
+    bytes_per_launch = n * (RAY_BYTES + HIT_BYTES) + nodes * NODE_BYTES + tris * TRI_BYTES
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("k_closest_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "closest-hit Mrays/s (1M-triangle soup, 1920x1080 primary rays, hit ids bit-exact vs reference BVH)",
+        "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[1]: {scene.n_triangles}-triangle soup (seed 12345), {args.width}x{args.height} pixel-centre primary rays per GPU, closest hit",
+                   "rays_per_step_per_gpu": n, "bvh4_nodes": core.stats().bvh4_nodes},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "kernel": "k_closest", "kernel_ms": round(kernel_ms, 4),
+                     "algorithmic_bytes_per_ray": round(bytes_per_launch / n, 1),
+                     "nodes_per_ray": round(nodes / n, 2), "tris_per_ray": round(tris / n, 2)},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(pkg, scene, cam, args)
+    if not args.no_pathtrace:
+        pt = pathtrace_side(pkg, scenes, lib, core, torch, dist, world, rank, dev, args)
+        if pt:
+            out.update(pt)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pkg, scene, cam, args):
+    """The CPU oracle (a port of the reference's BVH traversal, RTBase/Geometry.h:506-566)
+    on this box's host cores, over every 2nd ray of the same batch."""
+    pyoracle = importlib.import_module("oracle.pyoracle")
+    orc = pyoracle.Oracle(pkg)
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 8, 16)
+    osc = orc.scene(scene)
+    osc.set_camera(cam)
+    ys, xs = np.mgrid[0:args.height, 0:args.width]
+    xy = np.stack([xs.ravel() + 0.5, ys.ravel() + 0.5], 1).astype(np.float32)[::2]
+    rays = osc.generate_rays(xy)
+    t0 = time.perf_counter()
+    osc.trace_closest(rays, threads=threads)
+    dt = time.perf_counter() - t0
+    osc.close()
+    return {"value": round(len(rays) / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"every 2nd ray of the batch ({len(rays)} rays), {threads} threads, BVH build excluded"}
+
+
+def pathtrace_side(pkg, scenes, lib, core, torch, dist, world, rank, dev, args):
+    """1080p path tracing of the mixed-material scene under the environment map
+    (BASELINE.json configs[2]); samples are split over the ranks (shard_mode 2) and the films
+    summed with one RCCL all-reduce at the end."""
+    try:
+        scene = scenes.mixed_scene(128)
+        core.upload_scene(scene)
+        cam = pkg.look_at(lib, width=args.width, height=args.height, **scenes.mixed_camera())
+        core.set_camera(cam)
+        st = pkg.make_settings(total_spp=args.pt_spp * world, seed=1, shard_mode=2 if world > 1 else 0,
+                               shard_rank=rank, shard_world=world)
+        core.set_settings(st)
+        core.clear()
+        core.render_passes(2)          # warm-up
+        core.clear()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        core.render_passes(args.pt_spp)
+        if world > 1:
+            ptr, nfl = core.film_device()
+            film = torch.empty(nfl, dtype=torch.float32, device=dev)
+            ctypes.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(ctypes.c_void_p(film.data_ptr()), ctypes.c_void_p(ptr),
+                                                                   ctypes.c_size_t(nfl * 4), 3)
+            dist.all_reduce(film)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        s = core.stats()
+        return {"pathtrace_spp_per_s": round(args.pt_spp * world / dt, 3),
+                "pathtrace_config": {"workload": f"configs[2]: mixed Diffuse/Mirror/Glass/Conductor/Plastic scene ({scene.n_triangles} triangles) + 1024x512 env-map MIS, {args.width}x{args.height}, maxBounces 5",
+                                     "spp_timed": args.pt_spp * world, "parallelism": f"spp split x{world} + film all-reduce" if world > 1 else "1 GPU"}}
+    except pkg.RtxError as e:
+        return {"pathtrace_spp_per_s": None, "pathtrace_error": str(e)}
+
+
+if __name__ == "__main__":
+    main()

@@ -179,6 +179,10 @@ int rtx_get_spp(rtx_ctx* ctx, int* spp);
  * tile_samples may be NULL; otherwise it receives ceil(W/16)*ceil(H/16) entries. */
 int rtx_film_read(rtx_ctx* ctx, float* rgb_sums, int* spp, uint32_t* tile_samples);
 
+/* Restore an accumulated film and its sample count (resume of a progressive render, or a
+ * film prepared by the caller); the inverse of rtx_film_read. */
+int rtx_film_write(rtx_ctx* ctx, const float* rgb_sums, int spp);
+
 /* Device address of the film accumulator (W*H*3 floats) and of the tile-sample table, for
  * callers that combine films across GPUs with a collective (no reference counterpart). */
 int rtx_film_device(rtx_ctx* ctx, void** film_dev, size_t* n_floats);

@@ -33,8 +33,9 @@ namespace orc {
 
 // Windows <minwindef.h> function-like macros the reference's Renderer.h relies on
 // (RTBase/Renderer.h:92,156,237,...): note the NaN behaviour (second operand wins).
-template <class A, class B> static inline auto wmin(A a, B b) -> decltype(a < b ? a : b) { return (a < b) ? a : b; }
-template <class A, class B> static inline auto wmax(A a, B b) -> decltype(a > b ? a : b) { return (a > b) ? a : b; }
+static inline float wmin(float a, float b) { return (a < b) ? a : b; }
+static inline float wmax(float a, float b) { return (a > b) ? a : b; }
+static inline unsigned wmin(unsigned a, unsigned b) { return (a < b) ? a : b; }
 
 static constexpr float kEps = 0.001f;     // EPSILON, RTBase/Geometry.h:54
 static constexpr float kTriEps = 1e-8f;   // Triangle::epsilon, RTBase/Geometry.h:72

@@ -140,7 +140,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "rtx_clear": [vp], "rtx_render_passes": [vp, C.c_int], "rtx_get_spp": [vp, C.POINTER(C.c_int)],
         "rtx_set_spp": [vp, C.c_int],
         "rtx_film_read": [vp, vp, C.POINTER(C.c_int), vp],
-        "rtx_film_device": [vp, C.POINTER(vp), C.POINTER(sz)],
+        "rtx_film_device": [vp, C.POINTER(vp), C.POINTER(sz)], "rtx_film_write": [vp, vp, C.c_int],
         "rtx_tile_samples_device": [vp, C.POINTER(vp), C.POINTER(sz)], "rtx_update_tile_samples": [vp],
         "rtx_trace_closest": [vp, vp, sz, vp], "rtx_trace_closest_device": [vp, vp, sz, vp],
         "rtx_trace_visible": [vp, vp, sz, vp], "rtx_trace_visible_device": [vp, vp, sz, vp],
@@ -257,6 +257,11 @@ class Core:
         spp = C.c_int()
         self._check(self.lib.rtx_film_read(self.ctx, rgb.ctypes.data, C.byref(spp), tiles.ctypes.data))
         return rgb, spp.value, tiles
+
+    def film_write(self, rgb, spp: int):
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        assert rgb.shape == (self.height, self.width, 3)
+        self._check(self.lib.rtx_film_write(self.ctx, rgb.ctypes.data, spp))
 
     def film_device(self):
         p, n = C.c_void_p(), C.c_size_t()

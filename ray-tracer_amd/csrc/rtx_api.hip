@@ -228,6 +228,17 @@ int rtx_film_read(rtx_ctx* c, float* rgb, int* spp, uint32_t* tiles)
     return RTX_OK;
 }
 
+int rtx_film_write(rtx_ctx* c, const float* rgb, int spp)
+{
+    CTX_TRY(c);
+    if (!c->have_camera) return fail(RTX_ERR_STATE, "no camera set");
+    if (!rgb || spp < 0) return fail(RTX_ERR_INVALID, "bad argument");
+    HIP_TRY(hipMemcpyAsync(c->b_film.p, rgb, (size_t)c->cam.width * c->cam.height * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->spp = spp;
+    return RTX_OK;
+}
+
 int rtx_film_device(rtx_ctx* c, void** p, size_t* n)
 {
     if (!c || !p) return fail(RTX_ERR_INVALID, "null argument");

@@ -53,6 +53,28 @@ __global__ __launch_bounds__(kBlock) void k_closest(DeviceScene sc, const rtx_ra
     if (COUNT) { atomicAdd(&counters[0], (unsigned long long)cnt.nodes); atomicAdd(&counters[1], (unsigned long long)cnt.tris); }
 }
 
+// Closest hit for the live paths of a wavefront stage: rays[queue[i]], i < *n_dev (the
+// queue length stays on the device).
+__global__ __launch_bounds__(kBlock) void k_closest_q(DeviceScene sc, const rtx_ray* __restrict__ rays, const uint32_t* __restrict__ queue,
+                                                      const uint32_t* __restrict__ n_dev, rtx_hit* __restrict__ hits, uint2* spill, uint32_t spill_stride)
+{
+    __shared__ uint2 lds[kBlock * kLdsStack];
+    LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
+    const uint32_t n = *n_dev;
+    for (uint32_t i = global_thread(); i < n; i += gridDim.x * kBlock) {
+        const uint32_t idx = queue[i];
+        const rtx_ray r = rays[idx];
+        HitRec best;
+        traverse<false, false, kBlock, kLdsStack>(sc, stk, r.o[0], r.o[1], r.o[2], r.d[0], r.d[1], r.d[2], 0.0f, best, nullptr);
+        rtx_hit h;
+        if (best.pos != 0xFFFFFFFFu) {
+            h.id = __float_as_uint(sc.tris[best.pos].q0.w);
+            h.t = best.t; h.alpha = best.u; h.beta = best.v; h.gamma = 1.0f - (best.u + best.v);
+        } else { h.id = 0xFFFFFFFFu; h.t = FLT_MAX; h.alpha = 0; h.beta = 0; h.gamma = 0; }
+        hits[idx] = h;
+    }
+}
+
 // Scene::visible, RTBase/Scene.h:170-178, for one segment
 template <int BLOCK, int LDS_N>
 __device__ __forceinline__ bool segment_visible(const DeviceScene& sc, LaneStack<BLOCK, LDS_N>& stk,

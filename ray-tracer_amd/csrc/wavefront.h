@@ -1,10 +1,692 @@
-// wavefront.h — placeholder until the wavefront integrators land (replaced in the next commit)
+// wavefront.h — progressive rendering as a wavefront of kernels.
+//
+// One call of wavefront_render_pass() is one RayTracer::renderMT() (RTBase/Renderer.h:753-782):
+// one sample per active pixel for path tracing and instant radiosity, one light path per
+// pixel for light tracing. Instead of recursing per pixel, every stage is a kernel over a
+// queue of live paths:
+//
+//   ray generation -> [ closest hit -> shade (NEE + BSDF sample) -> shadow rays ]* -> film
+//
+// Queues are compacted with a wave64 ballot + one atomic per wave; queue lengths stay on
+// the device (kernels read them), so a pass needs no host synchronisation.
+// Path state is structure-of-arrays, indexed by path slot; slot i belongs to the 16x16
+// reference tile i/256 (RTBase/Renderer.h:38), wave i/64 covers an 8x8 pixel block.
 #pragma once
+
 #include "context.h"
+#include "shade.h"
+#include "trace_kernels.h"
+
 namespace rtx {
-struct WavefrontBuffers {};
-inline void wavefront_release(rtx_ctx*) {}
-inline int wavefront_resize(rtx_ctx*) { return RTX_OK; }
-inline int wavefront_render_pass(rtx_ctx*) { return RTX_ERR_STATE; }
-inline int wavefront_tile_samples(rtx_ctx*) { return RTX_ERR_STATE; }
+
+constexpr uint32_t kFlagCanHitLight = 1u;   // emission counts at the next hit (Renderer.h:487,516)
+constexpr uint32_t kFlagStarted = 2u;       // slot carries a sample this pass
+constexpr int kCounterWords = 256;
+constexpr int kShadowCounterBase = 96;
+
+struct WfPtrs {
+    rtx_ray* ray; rtx_hit* hit;
+    float* T;          // [P][3] path throughput
+    float* L;          // [P][3] radiance of the sample (light tracing / VPL: emitted Le of the path)
+    float* xy;         // [P][2] film position of the sample
+    uint32_t* key; uint32_t* dim; float* mis; uint32_t* flags;
+    uint32_t* qa; uint32_t* qb;       // live-path queues (ping-pong)
+    uint32_t* cnt;                    // [kCounterWords] queue lengths, zeroed per pass
+    float* sseg;       // [P][6] shadow segment p1 -> p2
+    float* sval;       // [P][3] contribution carried by the shadow ray
+    float* sxy;        // [P][2] splat position (light tracing)
+    uint32_t* spath;   // [P]    path slot the contribution belongs to
+    float* vpl;        // [V][10] x(3) n(3) Le(3) valid
+    uint32_t* vpl_total;
+    float* film; uint32_t* tile_samples;
+    uint32_t P, W, H, tiles_x, n_tiles, vpl_slots;
+};
+
+struct WavefrontBuffers {
+    DevBuf ray, hit, T, L, xy, key, dim, mis, flags, qa, qb, cnt, sseg, sval, sxy, spath, vpl, vpl_total;
+    WfPtrs p{};
+    uint32_t vpl_capacity = 0;
+};
+
+struct PassParams {
+    rtx_settings st; int spp; uint32_t sample_index; uint32_t depth;
+};
+
+// ---- small device helpers -------------------------------------------------------------------
+
+// Append to a queue: one atomic per wave, lanes take consecutive places.
+__device__ __forceinline__ uint32_t queue_slot(bool push, uint32_t* counter)
+{
+    const unsigned long long mask = __ballot(push);
+    if (!push) return 0xFFFFFFFFu;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader, 64);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
+
+__device__ __forceinline__ void slot_pixel(uint32_t slot, uint32_t tiles_x, uint32_t& tile, uint32_t& x, uint32_t& y)
+{
+    tile = slot >> 8;
+    const uint32_t j = slot & 255u, w = j >> 6, l = j & 63u;
+    x = (tile % tiles_x) * 16u + (((w & 1u) << 3) | (l & 7u));
+    y = (tile / tiles_x) * 16u + (((w >> 1) << 3) | (l >> 3));
+}
+
+__device__ __forceinline__ bool tile_active(const WfPtrs& w, const PassParams& pp, uint32_t tile)
+{
+    const rtx_settings& s = pp.st;
+    // processTile's skip, RTBase/Renderer.h:682-687
+    if (pp.spp > (int)s.init_spp && pp.spp > (int)w.tile_samples[tile] && s.algorithm != RTX_AL_LIGHT_TRACE) return false;
+    if (s.shard_mode == 1 && s.shard_world > 1 && (int)(tile % (uint32_t)s.shard_world) != s.shard_rank) return false;
+    return true;
+}
+
+__device__ __forceinline__ void st3(float* p, C3 c) { p[0] = c.r; p[1] = c.g; p[2] = c.b; }
+__device__ __forceinline__ void st3(float* p, V3 c) { p[0] = c.x; p[1] = c.y; p[2] = c.z; }
+
+// Film::splat, RTBase/Imaging.h:318-340 (filters :146-222). Float atomics: with the box
+// filter a pixel normally receives one sample per pass, but px = x + r can round up into
+// the next pixel, and the wide filters and light tracing write anywhere.
+__device__ __forceinline__ float filter_gauss(float d) { const float a = 2.5f; const float t2 = expf(-a * (2 * 2)); return expf(-a * (d * d)) - t2; }
+__device__ __forceinline__ float filter_mitchell(float d)
+{
+    const float B = 1.0f / 3.0f, C = 1.0f / 3.0f;
+    const float a1 = (1.0f / 6.0f) * (12 - 9 * B - 6 * C), a2 = (-18 + 12 * B + 6 * C), a3 = (6 - 2 * B);
+    const float b1 = (1.0f / 6.0f) * (-B - 6 * C), b2 = (6 * B + 30 * C), b3 = (-12 * B - 48 * C), b4 = (8 * B + 24 * C);
+    d = fabsf(d);
+    if (d >= 2) return 0;
+    float ds = d * d, dc = ds * d;
+    if (d >= 0 && d < 1) return a1 * dc + a2 * ds + a3;
+    return b1 * dc + b2 * ds + b3 * d + b4;
+}
+__device__ __forceinline__ float filter_weight(int filter, float x, float y)
+{
+    if (filter == RTX_FT_BOX) return (fabsf(x) <= 1.0f && fabsf(y) <= 1.0f) ? 1.0f : 0.0f;
+    if (filter == RTX_FT_GAUSSIAN) return filter_gauss(x) * filter_gauss(y);
+    return filter_mitchell(x) * filter_mitchell(y);
+}
+__device__ __forceinline__ void film_splat(float* film, int W, int H, int filter, float x, float y, C3 L)
+{
+    const int size = filter == RTX_FT_BOX ? 0 : 2;
+    float total = 0;
+    for (int i = -size; i <= size; i++) for (int j = -size; j <= size; j++) {
+        int px = (int)x + j, py = (int)y + i;
+        if (px >= 0 && px < W && py >= 0 && py < H) total += filter_weight(filter, px - x, py - y);
+    }
+    for (int i = -size; i <= size; i++) for (int j = -size; j <= size; j++) {
+        int px = (int)x + j, py = (int)y + i;
+        if (px >= 0 && px < W && py >= 0 && py < H) {
+            float wgt = filter_weight(filter, px - x, py - y);
+            C3 v = L * wgt / total;
+            float* f = film + 3 * ((size_t)py * W + px);
+            atomicAdd(f, v.r); atomicAdd(f + 1, v.g); atomicAdd(f + 2, v.b);
+        }
+    }
+}
+
+// Next-event estimation of RayTracer::computeDirect, RTBase/Renderer.h:417-474, up to the
+// visibility test: returns true and fills the shadow segment + the value the path gains if
+// the segment turns out visible.
+__device__ __forceinline__ bool direct_request(const DeviceScene& sc, const Shading& sd, Rng& rng, bool useMis, float misPdf,
+                                               V3& p2, C3& value)
+{
+    if (isPureSpecular(*sd.mat)) return false;
+    if (sc.n_lights == 0) return false;
+    float pmf; const LightDev& light = sample_light(sc, rng, pmf);
+    float pdf; C3 emitted; V3 p = light_sample(sc, light, rng, emitted, pdf);
+    pdf *= pmf;
+    if (light.kind == 0) {
+        V3 wi = p - sd.x; float lsq = lengthSq(wi); wi = normalize(wi);
+        float g = (wmax(dot(wi, sd.sNormal), 0.0f) * wmax(-dot(wi, ld3(light.gnormal)), 0.0f)) / lsq;
+        if (g > 0) { p2 = p; value = bsdf_evaluate(sc, sd, wi) * emitted * g / pdf; return true; }
+    } else {
+        V3 wi = normalize(p);
+        float g = wmax(dot(wi, sd.sNormal), 0.0f);
+        if (g > 0) {
+            p2 = sd.x + (p * 1000.0f);
+            float weight = useMis ? pdf / (pdf + misPdf) : 1.0f;
+            value = bsdf_evaluate(sc, sd, wi) * emitted * g * weight / pdf;
+            return true;
+        }
+    }
+    return false;
+}
+
+// ---- path tracing ---------------------------------------------------------------------------
+
+// Per-sample set-up of processTile, RTBase/Renderer.h:695-732 (and the pixel-centre variant
+// for the draw modes, :699-703).
+__global__ __launch_bounds__(kBlock) void k_raygen(WfPtrs w, CameraDev cam, PassParams pp)
+{
+    const uint32_t slot = global_thread();
+    bool active = false; uint32_t tile = 0, x = 0, y = 0;
+    if (slot < w.P) {
+        slot_pixel(slot, w.tiles_x, tile, x, y);
+        active = x < w.W && y < w.H && tile_active(w, pp, tile);
+    }
+    if (slot < w.P) w.flags[slot] = 0;
+    if (active) {
+        Rng rng; rng.key = rtx_rng_key(pp.st.seed, RTX_STREAM_CAMERA, y * w.W + x, pp.sample_index); rng.dim = 0;
+        float px, py;
+        if (pp.st.draw_mode != RTX_DM_ALGORITHM) { px = x + 0.5f; py = y + 0.5f; }
+        else { px = x + rng.next(); py = y + rng.next(); }
+        float dx, dy, dz; camera_ray(cam, px, py, dx, dy, dz);
+        rtx_ray r; r.o[0] = cam.origin[0]; r.o[1] = cam.origin[1]; r.o[2] = cam.origin[2]; r.d[0] = dx; r.d[1] = dy; r.d[2] = dz;
+        w.ray[slot] = r;
+        w.xy[2 * slot] = px; w.xy[2 * slot + 1] = py;
+        w.key[slot] = rng.key; w.dim[slot] = rng.dim; w.mis[slot] = 0.0f;
+        w.T[3 * slot] = 1.0f; w.T[3 * slot + 1] = 1.0f; w.T[3 * slot + 2] = 1.0f;
+        w.L[3 * slot] = 0.0f; w.L[3 * slot + 1] = 0.0f; w.L[3 * slot + 2] = 0.0f;
+        w.flags[slot] = kFlagStarted | (pp.st.can_hit_light ? kFlagCanHitLight : 0u);
+    }
+    uint32_t q = queue_slot(active, &w.cnt[0]);
+    if (active) w.qa[q] = slot;
+}
+
+// One depth of RayTracer::pathTrace, RTBase/Renderer.h:476-526, for every live path.
+__global__ __launch_bounds__(kBlock) void k_pt_shade(WfPtrs w, DeviceScene sc, PassParams pp, const uint32_t* __restrict__ qin, uint32_t* qout)
+{
+    const uint32_t n = w.cnt[pp.depth];
+    const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+    for (uint32_t it = 0; it < rounds; it++) {
+        const uint32_t i = it * gridDim.x * kBlock + global_thread();
+        bool cont = false, shadow = false; uint32_t slot = 0; V3 p2 = mk(0, 0, 0); C3 sval = mkc(0, 0, 0); V3 sx = mk(0, 0, 0);
+        if (i < n) {
+            slot = qin[i];
+            const rtx_hit h = w.hit[slot]; const rtx_ray r = w.ray[slot];
+            C3 T = ldc(w.T + 3 * slot); C3 L = ldc(w.L + 3 * slot);
+            const uint32_t flags = w.flags[slot]; const float misPdf = w.mis[slot];
+            const V3 o = ld3(r.o), d = ld3(r.d);
+            if (h.t < FLT_MAX) {
+                Shading sd; shading_data(sc, h, o, d, sd);
+                if (sd.mat->is_light) {
+                    if (flags & kFlagCanHitLight) { L = L + T * ldc(sd.mat->emission); st3(w.L + 3 * slot, L); }
+                } else {
+                    Rng rng; rng.key = w.key[slot]; rng.dim = w.dim[slot];
+                    C3 dv;
+                    if (direct_request(sc, sd, rng, pp.st.use_mis != 0, misPdf, p2, dv)) { shadow = true; sval = T * dv; sx = sd.x; }
+                    if (pp.depth < pp.st.max_bounces) {
+                        float rr = wmin(lum(T), 0.9f);
+                        if (!(rr < rng.next())) {
+                            T = T / rr;
+                            C3 bs; float pdf; V3 wi = bsdf_sample(sc, sd, rng, bs, pdf);
+                            T = T * bs * fabsf(dot(wi, sd.sNormal)) / pdf;
+                            V3 no = sd.x + (wi * kEps);
+                            rtx_ray nr; nr.o[0] = no.x; nr.o[1] = no.y; nr.o[2] = no.z; nr.d[0] = wi.x; nr.d[1] = wi.y; nr.d[2] = wi.z;
+                            w.ray[slot] = nr; st3(w.T + 3 * slot, T); w.mis[slot] = pdf;
+                            w.flags[slot] = (flags & ~kFlagCanHitLight) | (isPureSpecular(*sd.mat) ? kFlagCanHitLight : 0u);
+                            cont = true;
+                        }
+                    }
+                    w.dim[slot] = rng.dim;
+                }
+            } else {
+                // Renderer.h:519-525
+                if (pp.depth == 0) L = L + background_evaluate(sc, d);
+                else {
+                    float pdf = background_pdf(sc, d);
+                    float weight = pp.st.use_mis ? pdf / (pdf + misPdf) : 1.0f;
+                    L = L + background_evaluate(sc, d) * T * weight / pdf;
+                }
+                st3(w.L + 3 * slot, L);
+            }
+        }
+        uint32_t qs = queue_slot(shadow, &w.cnt[kShadowCounterBase + pp.depth]);
+        if (shadow) {
+            float* s = w.sseg + 6 * (size_t)qs; s[0] = sx.x; s[1] = sx.y; s[2] = sx.z; s[3] = p2.x; s[4] = p2.y; s[5] = p2.z;
+            st3(w.sval + 3 * (size_t)qs, sval); w.spath[qs] = slot;
+        }
+        uint32_t qc = queue_slot(cont, &w.cnt[pp.depth + 1]);
+        if (cont) qout[qc] = slot;
+    }
+}
+
+// Shadow rays of one depth: a visible segment adds its value to the path's radiance
+// (Renderer.h:448-452, 463-469).
+__global__ __launch_bounds__(kBlock) void k_shadow_accumulate(WfPtrs w, DeviceScene sc, uint32_t counter_index, uint2* spill, uint32_t spill_stride)
+{
+    __shared__ uint2 lds[kBlock * kLdsStack];
+    LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
+    const uint32_t n = w.cnt[counter_index];
+    for (uint32_t i = global_thread(); i < n; i += gridDim.x * kBlock) {
+        const float* s = w.sseg + 6 * (size_t)i;
+        if (segment_visible(sc, stk, s[0], s[1], s[2], s[3], s[4], s[5])) {
+            const uint32_t slot = w.spath[i];
+            C3 L = ldc(w.L + 3 * slot) + ldc(w.sval + 3 * (size_t)i);
+            st3(w.L + 3 * slot, L);
+        }
+    }
+}
+
+// film->splat(px, py, col) for every sample of the pass, Renderer.h:745
+__global__ __launch_bounds__(kBlock) void k_film_accumulate(WfPtrs w, int filter)
+{
+    const uint32_t slot = global_thread();
+    if (slot >= w.P || !(w.flags[slot] & kFlagStarted)) return;
+    film_splat(w.film, (int)w.W, (int)w.H, filter, w.xy[2 * slot], w.xy[2 * slot + 1], ldc(w.L + 3 * slot));
+}
+
+// ---- draw modes: RayTracer::direct / albedo / viewNormals, RTBase/Renderer.h:536-575 -------
+__global__ __launch_bounds__(kBlock) void k_dm_shade(WfPtrs w, DeviceScene sc, PassParams pp)
+{
+    const uint32_t n = w.cnt[0];
+    const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+    for (uint32_t it = 0; it < rounds; it++) {
+        const uint32_t i = it * gridDim.x * kBlock + global_thread();
+        bool shadow = false; uint32_t slot = 0; V3 p2 = mk(0, 0, 0), sx = mk(0, 0, 0); C3 sval = mkc(0, 0, 0);
+        if (i < n) {
+            slot = w.qa[i];
+            const rtx_hit h = w.hit[slot]; const rtx_ray r = w.ray[slot];
+            const V3 o = ld3(r.o), d = ld3(r.d);
+            C3 L = mkc(0, 0, 0);
+            if (h.t < FLT_MAX) {
+                Shading sd; shading_data(sc, h, o, d, sd);
+                if (pp.st.draw_mode == RTX_DM_NORMALS) L = mkc(fabsf(sd.sNormal.x), fabsf(sd.sNormal.y), fabsf(sd.sNormal.z));
+                else if (sd.mat->is_light) L = ldc(sd.mat->emission);
+                else if (pp.st.draw_mode == RTX_DM_ALBEDO) L = bsdf_evaluate(sc, sd, mk(0, 1, 0));
+                else {
+                    Rng rng; rng.key = w.key[slot]; rng.dim = w.dim[slot];
+                    C3 dv;
+                    if (direct_request(sc, sd, rng, pp.st.use_mis != 0, 0.0f, p2, dv)) { shadow = true; sval = dv; sx = sd.x; }
+                    w.dim[slot] = rng.dim;
+                }
+            } else if (pp.st.draw_mode != RTX_DM_NORMALS) L = background_evaluate(sc, d);
+            st3(w.L + 3 * slot, L);
+        }
+        uint32_t qs = queue_slot(shadow, &w.cnt[kShadowCounterBase]);
+        if (shadow) {
+            float* s = w.sseg + 6 * (size_t)qs; s[0] = sx.x; s[1] = sx.y; s[2] = sx.z; s[3] = p2.x; s[4] = p2.y; s[5] = p2.z;
+            st3(w.sval + 3 * (size_t)qs, sval); w.spath[qs] = slot;
+        }
+    }
+}
+
+// ---- light tracing: RTBase/Renderer.h:308-411 ----------------------------------------------
+
+// Camera::projectOntoCamera, RTBase/Scene.h:61-75
+__device__ __forceinline__ bool project_onto_camera(const CameraDev& c, V3 p, float& x, float& y)
+{
+    const float* m = c.camera_to_view;
+    V3 pv = mk((p.x * m[0] + p.y * m[1] + p.z * m[2]) + m[3], (p.x * m[4] + p.y * m[5] + p.z * m[6]) + m[7], (p.x * m[8] + p.y * m[9] + p.z * m[10]) + m[11]);
+    const float* q = c.proj;
+    V3 v1 = mk((pv.x * q[0] + pv.y * q[1] + pv.z * q[2]) + q[3], (pv.x * q[4] + pv.y * q[5] + pv.z * q[6]) + q[7], (pv.x * q[8] + pv.y * q[9] + pv.z * q[10]) + q[11]);
+    float ww = (q[12] * pv.x) + (q[13] * pv.y) + (q[14] * pv.z) + q[15];
+    ww = 1.0f / ww;
+    V3 pp = v1 * ww;
+    x = (pp.x + 1.0f) * 0.5f;
+    y = (pp.y + 1.0f) * 0.5f;
+    if (x < 0 || x > 1.0f || y < 0 || y > 1.0f) return false;
+    x = x * c.width;
+    y = 1.0f - y;
+    y = y * c.height;
+    return true;
+}
+
+// RayTracer::connectToCamera, RTBase/Renderer.h:308-334, up to the visibility test
+__device__ __forceinline__ bool connect_request(const CameraDev& cam, V3 p, V3 n, C3 col, float& x, float& y, C3& value)
+{
+    if (!project_onto_camera(cam, p, x, y)) return false;
+    V3 toCam = ld3(cam.origin) - p;
+    float lsq = lengthSq(toCam);
+    toCam = normalize(toCam);
+    float cosS = dot(toCam, n), cosC = dot(toCam, ld3(cam.view_dir));
+    float g = wmax(cosS, 0.0f) * wmax(-cosC, 0.0f) / lsq;
+    if (!(g > 0)) return false;
+    float c2 = (cosC * cosC);
+    float we = 1.0f / (c2 * c2 * cam.afilm);
+    value = col * we * g;
+    return true;
+}
+
+__device__ __forceinline__ void push_connection(const WfPtrs& w, bool want, uint32_t counter, V3 p, const CameraDev& cam, float x, float y, C3 value)
+{
+    uint32_t qs = queue_slot(want, &w.cnt[counter]);
+    if (want) {
+        float* s = w.sseg + 6 * (size_t)qs; s[0] = p.x; s[1] = p.y; s[2] = p.z; s[3] = cam.origin[0]; s[4] = cam.origin[1]; s[5] = cam.origin[2];
+        st3(w.sval + 3 * (size_t)qs, value); w.sxy[2 * (size_t)qs] = x; w.sxy[2 * (size_t)qs + 1] = y;
+    }
+}
+
+// RayTracer::lightTrace, RTBase/Renderer.h:379-411: one light path per pixel slot
+__global__ __launch_bounds__(kBlock) void k_lt_emit(WfPtrs w, DeviceScene sc, CameraDev cam, PassParams pp)
+{
+    const uint32_t slot = global_thread();
+    bool active = false, conn = false; uint32_t tile = 0, x = 0, y = 0; V3 p = mk(0, 0, 0); float fx = 0, fy = 0; C3 cval = mkc(0, 0, 0);
+    if (slot < w.P) {
+        slot_pixel(slot, w.tiles_x, tile, x, y);
+        active = x < w.W && y < w.H && tile_active(w, pp, tile) && sc.n_lights > 0;
+        w.flags[slot] = 0;
+    }
+    if (active) {
+        Rng rng; rng.key = rtx_rng_key(pp.st.seed, RTX_STREAM_LIGHT, y * w.W + x, pp.sample_index); rng.dim = 0;
+        float pmf; const LightDev& light = sample_light(sc, rng, pmf);
+        float pdfPos, pdfDir;
+        p = light_sample_position(sc, light, rng, pdfPos);
+        V3 wi = light_sample_direction(light, rng, pdfDir);
+        V3 nLight = light.kind == 0 ? ld3(light.gnormal) : -wi;                     // Light::normal, Lights.h:60,113,373
+        float cosTheta = dot(wi, nLight);
+        C3 Le = light_evaluate(sc, light, -wi) / (pmf * pdfPos);
+        if (pp.st.can_hit_light) conn = connect_request(cam, p, nLight, Le, fx, fy, cval);
+        if (light.kind == 0) Le = Le * cosTheta;
+        rtx_ray r; r.o[0] = p.x; r.o[1] = p.y; r.o[2] = p.z; r.d[0] = wi.x; r.d[1] = wi.y; r.d[2] = wi.z;
+        w.ray[slot] = r; st3(w.L + 3 * slot, Le);
+        w.T[3 * slot] = 1.0f; w.T[3 * slot + 1] = 1.0f; w.T[3 * slot + 2] = 1.0f;
+        w.key[slot] = rng.key; w.dim[slot] = rng.dim;
+    }
+    push_connection(w, conn, kShadowCounterBase + 95, p, cam, fx, fy, cval);
+    // lightTracePath returns at once when maxBounces == 0 (Renderer.h:339)
+    bool live = active && pp.st.max_bounces > 0;
+    uint32_t q = queue_slot(live, &w.cnt[0]);
+    if (live) w.qa[q] = slot;
+}
+
+// One depth of RayTracer::lightTracePath, RTBase/Renderer.h:336-377
+__global__ __launch_bounds__(kBlock) void k_lt_shade(WfPtrs w, DeviceScene sc, CameraDev cam, PassParams pp, const uint32_t* __restrict__ qin, uint32_t* qout)
+{
+    const uint32_t n = w.cnt[pp.depth];
+    const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+    for (uint32_t it = 0; it < rounds; it++) {
+        const uint32_t i = it * gridDim.x * kBlock + global_thread();
+        bool cont = false, conn = false; uint32_t slot = 0; V3 hp = mk(0, 0, 0); float fx = 0, fy = 0; C3 cval = mkc(0, 0, 0);
+        if (i < n) {
+            slot = qin[i];
+            const rtx_hit h = w.hit[slot]; const rtx_ray r = w.ray[slot];
+            if (h.t < FLT_MAX) {
+                Shading sd; shading_data(sc, h, ld3(r.o), ld3(r.d), sd);
+                if (!(sd.mat->is_light || isPureSpecular(*sd.mat))) {
+                    C3 T = ldc(w.T + 3 * slot); const C3 Le = ldc(w.L + 3 * slot);
+                    V3 wi = normalize(ld3(cam.origin) - sd.x);
+                    C3 col = T * bsdf_evaluate(sc, sd, wi) * Le;
+                    conn = connect_request(cam, sd.x, sd.sNormal, col, fx, fy, cval); hp = sd.x;
+                    Rng rng; rng.key = w.key[slot]; rng.dim = w.dim[slot];
+                    float rr = wmin(lum(T), 0.9f);
+                    if (!(rr < rng.next())) {
+                        T = T / rr;
+                        C3 bs; float pdf; wi = bsdf_sample(sc, sd, rng, bs, pdf);
+                        T = T * bs * fabsf(dot(wi, sd.sNormal)) / pdf;
+                        V3 no = sd.x + (wi * kEps);
+                        rtx_ray nr; nr.o[0] = no.x; nr.o[1] = no.y; nr.o[2] = no.z; nr.d[0] = wi.x; nr.d[1] = wi.y; nr.d[2] = wi.z;
+                        w.ray[slot] = nr; st3(w.T + 3 * slot, T);
+                        cont = pp.depth + 1 < pp.st.max_bounces;
+                    }
+                    w.dim[slot] = rng.dim;
+                }
+            }
+        }
+        push_connection(w, conn, kShadowCounterBase + pp.depth, hp, cam, fx, fy, cval);
+        uint32_t qc = queue_slot(cont, &w.cnt[pp.depth + 1]);
+        if (cont) qout[qc] = slot;
+    }
+}
+
+// Camera connections of one stage: visible ones splat onto the film (Renderer.h:325-331)
+__global__ __launch_bounds__(kBlock) void k_lt_splat(WfPtrs w, DeviceScene sc, uint32_t counter_index, int filter, uint2* spill, uint32_t spill_stride)
+{
+    __shared__ uint2 lds[kBlock * kLdsStack];
+    LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
+    const uint32_t n = w.cnt[counter_index];
+    for (uint32_t i = global_thread(); i < n; i += gridDim.x * kBlock) {
+        const float* s = w.sseg + 6 * (size_t)i;
+        if (segment_visible(sc, stk, s[0], s[1], s[2], s[3], s[4], s[5]))
+            film_splat(w.film, (int)w.W, (int)w.H, filter, w.sxy[2 * (size_t)i], w.sxy[2 * (size_t)i + 1], ldc(w.sval + 3 * (size_t)i));
+    }
+}
+
+// ---- instant radiosity: RTBase/Renderer.h:124-302 -------------------------------------------
+
+__device__ __forceinline__ void vpl_store(const WfPtrs& w, uint32_t idx, V3 x, V3 n, C3 Le)
+{
+    float* v = w.vpl + 10 * (size_t)idx;
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = n.x; v[4] = n.y; v[5] = n.z; v[6] = Le.r; v[7] = Le.g; v[8] = Le.b; v[9] = 1.0f;
+}
+
+// Loop body of RayTracer::traceVPLs, RTBase/Renderer.h:176-207; VPL slot of path j at depth d
+// is j*(maxBounces+1)+d, which keeps the reference's list order (path by path, along the path)
+__global__ __launch_bounds__(kBlock) void k_vpl_emit(WfPtrs w, DeviceScene sc, PassParams pp, uint32_t n_paths)
+{
+    const uint32_t j = global_thread();
+    bool live = false;
+    if (j < n_paths && sc.n_lights > 0) {
+        Rng rng; rng.key = rtx_rng_key(pp.st.seed, RTX_STREAM_VPL, j, (uint32_t)pp.spp); rng.dim = 0;
+        float pmf; const LightDev& light = sample_light(sc, rng, pmf);
+        float pdfPos, pdfDir;
+        V3 p = light_sample_position(sc, light, rng, pdfPos);
+        V3 wi = light_sample_direction(light, rng, pdfDir);
+        V3 nLight = light.kind == 0 ? ld3(light.gnormal) : -wi;
+        float cosTheta = dot(wi, nLight);
+        C3 Le = light_evaluate(sc, light, -wi) * cosTheta / (pmf * pdfPos);
+        vpl_store(w, j * (pp.st.max_bounces + 1), p, nLight, Le);
+        rtx_ray r; r.o[0] = p.x; r.o[1] = p.y; r.o[2] = p.z; r.d[0] = wi.x; r.d[1] = wi.y; r.d[2] = wi.z;
+        w.ray[j] = r; st3(w.L + 3 * j, Le);
+        w.T[3 * j] = 1.0f; w.T[3 * j + 1] = 1.0f; w.T[3 * j + 2] = 1.0f;
+        w.key[j] = rng.key; w.dim[j] = rng.dim;
+        live = pp.st.max_bounces > 0;
+    }
+    uint32_t q = queue_slot(live, &w.cnt[0]);
+    if (live) w.qa[q] = j;
+}
+
+// One depth of RayTracer::VPLTracePath, RTBase/Renderer.h:124-168
+__global__ __launch_bounds__(kBlock) void k_vpl_shade(WfPtrs w, DeviceScene sc, PassParams pp, const uint32_t* __restrict__ qin, uint32_t* qout)
+{
+    const uint32_t n = w.cnt[pp.depth];
+    const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+    for (uint32_t it = 0; it < rounds; it++) {
+        const uint32_t i = it * gridDim.x * kBlock + global_thread();
+        bool cont = false; uint32_t j = 0;
+        if (i < n) {
+            j = qin[i];
+            const rtx_hit h = w.hit[j]; const rtx_ray r = w.ray[j];
+            if (h.t < FLT_MAX) {
+                Shading sd; shading_data(sc, h, ld3(r.o), ld3(r.d), sd);
+                if (!(sd.mat->is_light || isPureSpecular(*sd.mat))) {
+                    C3 T = ldc(w.T + 3 * j); const C3 Le = ldc(w.L + 3 * j);
+                    Rng rng; rng.key = w.key[j]; rng.dim = w.dim[j];
+                    C3 bs; float pdf; V3 wi = bsdf_sample(sc, sd, rng, bs, pdf);
+                    T = T * bs * fabsf(dot(wi, sd.sNormal)) / pdf;
+                    vpl_store(w, j * (pp.st.max_bounces + 1) + pp.depth + 1, sd.x, sd.sNormal, T * Le);
+                    float rr = wmin(lum(T), 0.9f);
+                    if (!(rr < rng.next())) {
+                        T = T / rr;
+                        V3 no = sd.x + (wi * kEps);
+                        rtx_ray nr; nr.o[0] = no.x; nr.o[1] = no.y; nr.o[2] = no.z; nr.d[0] = wi.x; nr.d[1] = wi.y; nr.d[2] = wi.z;
+                        w.ray[j] = nr; st3(w.T + 3 * j, T);
+                        cont = pp.depth + 1 < pp.st.max_bounces;
+                    }
+                    w.dim[j] = rng.dim;
+                }
+            }
+        }
+        uint32_t qc = queue_slot(cont, &w.cnt[pp.depth + 1]);
+        if (cont) qout[qc] = j;
+    }
+}
+
+__global__ void k_vpl_count(WfPtrs w)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint32_t c = 0;
+        for (uint32_t i = 0; i < w.vpl_slots; i++) c += w.vpl[10 * (size_t)i + 9] != 0.0f ? 1u : 0u;
+        *w.vpl_total = c;
+    }
+}
+
+// RayTracer::radiosityLightPass + radiosityComputeDirect, RTBase/Renderer.h:210-278: every
+// pixel gathers from every VPL, in list order
+__global__ __launch_bounds__(kBlock) void k_ir_gather(WfPtrs w, DeviceScene sc, PassParams pp, uint2* spill, uint32_t spill_stride)
+{
+    __shared__ uint2 lds[kBlock * kLdsStack];
+    LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
+    const uint32_t n = w.cnt[0];
+    const uint32_t total = *w.vpl_total;
+    for (uint32_t i = global_thread(); i < n; i += gridDim.x * kBlock) {
+        const uint32_t slot = w.qa[i];
+        const rtx_hit h = w.hit[slot]; const rtx_ray r = w.ray[slot];
+        C3 L = mkc(0, 0, 0);
+        if (h.t < FLT_MAX) {
+            Shading sd; shading_data(sc, h, ld3(r.o), ld3(r.d), sd);
+            if (isPureSpecular(*sd.mat)) L = mkc(0, 0, 0);
+            else if (sd.mat->is_light) L = pp.st.can_hit_light ? ldc(sd.mat->emission) : mkc(0, 0, 0);
+            else {
+                C3 acc = mkc(0, 0, 0);
+                for (uint32_t k = 0; k < w.vpl_slots; k++) {
+                    const float* v = w.vpl + 10 * (size_t)k;
+                    if (v[9] == 0.0f) continue;
+                    V3 vx = ld3(v), vn = ld3(v + 3);
+                    V3 wi = vx - sd.x; float lsq = lengthSq(wi); wi = normalize(wi);
+                    float g = (wmax(dot(wi, sd.sNormal), 0.0f) * wmax(-dot(wi, vn), 0.0f)) / lsq;
+                    if (g > 0 && segment_visible(sc, stk, sd.x.x, sd.x.y, sd.x.z, vx.x, vx.y, vx.z))
+                        acc = acc + bsdf_evaluate(sc, sd, wi) * ldc(v + 6) * g;
+                }
+                L = acc / (float)total;
+            }
+        } else L = background_evaluate(sc, ld3(r.d));
+        st3(w.L + 3 * slot, L);
+    }
+}
+
+// ---- adaptive sampling: RayTracer::calculateTileSamples, RTBase/Renderer.h:643-671 ----------
+// One lane per tile, summing in the reference's order (Film::getLums walks x outside, y
+// inside, RTBase/Imaging.h:376-385) so the truncated sample targets agree exactly.
+__global__ __launch_bounds__(kBlock) void k_tile_samples(WfPtrs w, int spp, uint32_t total_spp)
+{
+    const uint32_t i = global_thread();
+    if (i >= w.n_tiles) return;
+    const uint32_t sx = (i % w.tiles_x) * 16u, sy = (i / w.tiles_x) * 16u;
+    const uint32_t ex = min(sx + 16u, w.W), ey = min(sy + 16u, w.H);
+    const uint32_t count = (ex - sx) * (ey - sy);
+    float total = 0.0f;
+    for (uint32_t x = sx; x < ex; x++) for (uint32_t y = sy; y < ey; y++) total += lum(ldc(w.film + 3 * ((size_t)y * w.W + x)));
+    float mean = count == 0 ? 0.0f : total / (float)count;
+    float variance = 0.0f;
+    for (uint32_t x = sx; x < ex; x++) for (uint32_t y = sy; y < ey; y++) { float l = lum(ldc(w.film + 3 * ((size_t)y * w.W + x))); variance += (l - mean) * (l - mean); }
+    variance = count == 0 ? 0.0f : variance / (float)count;
+    float q = variance / (variance + mean * mean + kEps);
+    float weight = (q < kEps) ? kEps : (q > 1.0f) ? 1.0f : q;
+    w.tile_samples[i] = (uint32_t)((float)spp + (float)(total_spp - (uint32_t)spp) * weight);
+}
+
+// ---- host side --------------------------------------------------------------------------------
+
+inline void wavefront_release(rtx_ctx* c) { delete c->wf; c->wf = nullptr; }
+
+inline int wavefront_resize(rtx_ctx* c)
+{
+    if (!c->wf) c->wf = new WavefrontBuffers;
+    WavefrontBuffers& b = *c->wf;
+    const size_t P = (size_t)c->tiles_x * c->tiles_y * 256;
+#define RTX_ENS(buf, bytes) do { if ((buf).ensure(bytes) != hipSuccess) return RTX_ERR_NOMEM; } while (0)
+    RTX_ENS(b.ray, P * sizeof(rtx_ray)); RTX_ENS(b.hit, P * sizeof(rtx_hit)); RTX_ENS(b.T, P * 12); RTX_ENS(b.L, P * 12);
+    RTX_ENS(b.xy, P * 8); RTX_ENS(b.key, P * 4); RTX_ENS(b.dim, P * 4); RTX_ENS(b.mis, P * 4); RTX_ENS(b.flags, P * 4);
+    RTX_ENS(b.qa, P * 4); RTX_ENS(b.qb, P * 4); RTX_ENS(b.cnt, kCounterWords * 4);
+    RTX_ENS(b.sseg, P * 24); RTX_ENS(b.sval, P * 12); RTX_ENS(b.sxy, P * 8); RTX_ENS(b.spath, P * 4); RTX_ENS(b.vpl_total, 16);
+#undef RTX_ENS
+    WfPtrs& p = b.p;
+    p.ray = b.ray.as<rtx_ray>(); p.hit = b.hit.as<rtx_hit>(); p.T = b.T.as<float>(); p.L = b.L.as<float>(); p.xy = b.xy.as<float>();
+    p.key = b.key.as<uint32_t>(); p.dim = b.dim.as<uint32_t>(); p.mis = b.mis.as<float>(); p.flags = b.flags.as<uint32_t>();
+    p.qa = b.qa.as<uint32_t>(); p.qb = b.qb.as<uint32_t>(); p.cnt = b.cnt.as<uint32_t>();
+    p.sseg = b.sseg.as<float>(); p.sval = b.sval.as<float>(); p.sxy = b.sxy.as<float>(); p.spath = b.spath.as<uint32_t>();
+    p.vpl_total = b.vpl_total.as<uint32_t>();
+    p.film = c->b_film.as<float>(); p.tile_samples = c->b_tile_samples.as<uint32_t>();
+    p.P = (uint32_t)P; p.W = (uint32_t)c->cam.width; p.H = (uint32_t)c->cam.height; p.tiles_x = c->tiles_x; p.n_tiles = c->tiles_x * c->tiles_y;
+    // tileSamples.resize(totalTiles, 1), RTBase/Renderer.h:112
+    std::vector<uint32_t> ones(p.n_tiles, 1u);
+    if (hipMemcpy(c->b_tile_samples.p, ones.data(), ones.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return RTX_ERR_HIP;
+    return RTX_OK;
+}
+
+inline int wavefront_tile_samples(rtx_ctx* c)
+{
+    if (!c->wf) return RTX_ERR_STATE;
+    WfPtrs& w = c->wf->p;
+    hipLaunchKernelGGL(k_tile_samples, dim3((w.n_tiles + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, w, c->spp, c->settings.total_spp);
+    return hipGetLastError() == hipSuccess ? RTX_OK : RTX_ERR_HIP;
+}
+
+inline int wavefront_render_pass(rtx_ctx* c)
+{
+    if (!c->wf) return RTX_ERR_STATE;
+    WavefrontBuffers& b = *c->wf; WfPtrs& w = b.p; const rtx_settings& st = c->settings; hipStream_t s = c->stream;
+    const dim3 blk(kBlock), gridP((w.P + kBlock - 1) / kBlock), gridQ(std::min<uint32_t>((w.P + kBlock - 1) / kBlock, kMaxGridBlocks));
+    uint2* spill = c->b_spill.as<uint2>(); const uint32_t sstride = kMaxGridBlocks * kBlock;
+
+    c->spp++;                                            // Film::incrementSPP, RTBase/Imaging.h:403
+    PassParams pp; pp.st = st; pp.spp = c->spp; pp.depth = 0;
+    pp.sample_index = (st.shard_mode == 2 && st.shard_world > 1) ? (uint32_t)(c->spp - 1) * (uint32_t)st.shard_world + (uint32_t)st.shard_rank + 1u : (uint32_t)c->spp;
+    if (hipMemsetAsync(w.cnt, 0, kCounterWords * 4, s) != hipSuccess) return RTX_ERR_HIP;
+
+    auto closest = [&](const uint32_t* queue, uint32_t counter) {
+        hipLaunchKernelGGL(k_closest_q, gridQ, blk, 0, s, c->dscene, (const rtx_ray*)w.ray, queue, (const uint32_t*)(w.cnt + counter), w.hit, spill, sstride);
+    };
+    const bool algo = st.draw_mode == RTX_DM_ALGORITHM;
+
+    if (!algo) {
+        // RTBase/Renderer.h:699-720
+        hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
+        closest(w.qa, 0);
+        hipLaunchKernelGGL(k_dm_shade, gridQ, blk, 0, s, w, c->dscene, pp);
+        hipLaunchKernelGGL(k_shadow_accumulate, gridQ, blk, 0, s, w, c->dscene, (uint32_t)kShadowCounterBase, spill, sstride);
+        hipLaunchKernelGGL(k_film_accumulate, gridP, blk, 0, s, w, (int)st.filter);
+        c->stats.samples += (uint64_t)w.W * w.H;
+    } else if (st.algorithm == RTX_AL_PATH_TRACE) {
+        hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
+        uint32_t* qin = w.qa; uint32_t* qout = w.qb;
+        for (uint32_t d = 0; d <= st.max_bounces; d++) {
+            pp.depth = d;
+            closest(qin, d);
+            hipLaunchKernelGGL(k_pt_shade, gridQ, blk, 0, s, w, c->dscene, pp, (const uint32_t*)qin, qout);
+            hipLaunchKernelGGL(k_shadow_accumulate, gridQ, blk, 0, s, w, c->dscene, (uint32_t)(kShadowCounterBase + d), spill, sstride);
+            std::swap(qin, qout);
+        }
+        hipLaunchKernelGGL(k_film_accumulate, gridP, blk, 0, s, w, (int)st.filter);
+        c->stats.samples += (uint64_t)w.W * w.H;
+    } else if (st.algorithm == RTX_AL_LIGHT_TRACE) {
+        hipLaunchKernelGGL(k_lt_emit, gridP, blk, 0, s, w, c->dscene, c->dcam, pp);
+        hipLaunchKernelGGL(k_lt_splat, gridQ, blk, 0, s, w, c->dscene, (uint32_t)(kShadowCounterBase + 95), (int)st.filter, spill, sstride);
+        uint32_t* qin = w.qa; uint32_t* qout = w.qb;
+        for (uint32_t d = 0; d < st.max_bounces; d++) {
+            pp.depth = d;
+            closest(qin, d);
+            hipLaunchKernelGGL(k_lt_shade, gridQ, blk, 0, s, w, c->dscene, c->dcam, pp, (const uint32_t*)qin, qout);
+            hipLaunchKernelGGL(k_lt_splat, gridQ, blk, 0, s, w, c->dscene, (uint32_t)(kShadowCounterBase + d), (int)st.filter, spill, sstride);
+            std::swap(qin, qout);
+        }
+        c->stats.samples += (uint64_t)w.W * w.H;
+    } else {
+        // radiosityVplPass, RTBase/Renderer.h:280-302: numThreads x vplRaysPerTile light paths
+        const uint32_t n_paths = st.vpl_rays_per_tile * st.num_threads;
+        if (n_paths > w.P) return RTX_ERR_INVALID;
+        const uint32_t slots = n_paths * (st.max_bounces + 1);
+        if (b.vpl.ensure(std::max<size_t>((size_t)slots * 40, 16)) != hipSuccess) return RTX_ERR_NOMEM;
+        w.vpl = b.vpl.as<float>(); w.vpl_slots = slots;
+        if (slots && hipMemsetAsync(w.vpl, 0, (size_t)slots * 40, s) != hipSuccess) return RTX_ERR_HIP;
+        if (n_paths) {
+            hipLaunchKernelGGL(k_vpl_emit, dim3((n_paths + kBlock - 1) / kBlock), blk, 0, s, w, c->dscene, pp, n_paths);
+            uint32_t* qin = w.qa; uint32_t* qout = w.qb;
+            for (uint32_t d = 0; d < st.max_bounces; d++) {
+                pp.depth = d;
+                closest(qin, d);
+                hipLaunchKernelGGL(k_vpl_shade, gridQ, blk, 0, s, w, c->dscene, pp, (const uint32_t*)qin, qout);
+                std::swap(qin, qout);
+            }
+        }
+        hipLaunchKernelGGL(k_vpl_count, dim3(1), dim3(64), 0, s, w);
+        // per-pixel gather, RTBase/Renderer.h:730-745
+        pp.depth = 0;
+        if (hipMemsetAsync(w.cnt, 0, kCounterWords * 4, s) != hipSuccess) return RTX_ERR_HIP;
+        hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
+        closest(w.qa, 0);
+        hipLaunchKernelGGL(k_ir_gather, gridQ, blk, 0, s, w, c->dscene, pp, spill, sstride);
+        hipLaunchKernelGGL(k_film_accumulate, gridP, blk, 0, s, w, (int)st.filter);
+        c->stats.samples += (uint64_t)w.W * w.H;
+    }
+    if (hipGetLastError() != hipSuccess) return RTX_ERR_HIP;
+    // RTBase/Renderer.h:780-781
+    if (c->spp == (int)st.init_spp && st.algorithm != RTX_AL_LIGHT_TRACE && st.shard_mode != 2) return wavefront_tile_samples(c);
+    return RTX_OK;
+}
+
+} // namespace rtx

@@ -1,0 +1,184 @@
+"""GPU parity of the progressive renderer (rtx_render_passes) against the CPU oracle.
+
+Per-sample parity: the oracle is run with the core's counter sampler (include/rtx_rng.h),
+so pixel sample k of the HIP path and of the oracle consume the same random numbers in the
+same order; with the box filter the film after one pass IS the radiance of sample 1.
+Intersection is bit-exact; shading goes through sinf/cosf/powf/acosf/atan2f, whose device
+and glibc versions differ in the last bits, and the reference's recursion sums the bounce
+terms in the opposite order to the wavefront loop. Tolerance (stated per test): relative
+1e-4 on each channel against max(|oracle|, 1e-3), with at most 0.5 % of pixels allowed to
+differ more (a last-bit difference can flip a Russian-roulette / Fresnel / CDF decision).
+
+Converged parity: many samples against the oracle run with the reference's own
+per-thread MT19937 streams (independent randomness) — a statistical test.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4
+OUTLIER_FRACTION = 0.005
+
+
+def _setup(pkg, lib, core, orc, scene, cam_kw, w, h, **settings):
+    core.upload_scene(scene)
+    cam = pkg.look_at(lib, width=w, height=h, **cam_kw)
+    core.set_camera(cam)
+    st = pkg.make_settings(**settings)
+    core.set_settings(st)
+    core.clear()
+    osc = orc.scene(scene)
+    osc.set_camera(cam)
+    return st, osc
+
+
+def _outliers(got, want):
+    err = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
+    bad = (err > REL_TOL).any(axis=-1)
+    return float(bad.mean()), err
+
+
+def _assert_films_match(got, want, what, frac=OUTLIER_FRACTION):
+    assert np.isfinite(got).all() == np.isfinite(want).all()
+    g, w = np.nan_to_num(got, posinf=0, neginf=0), np.nan_to_num(want, posinf=0, neginf=0)
+    f, err = _outliers(g, w)
+    assert f <= frac, f"{what}: {f:.4%} of pixels beyond rel {REL_TOL} (median err {np.median(err):.2e})"
+
+
+@pytest.mark.parametrize("materials", ["diffuse", "mixed"])
+def test_path_trace_per_sample_parity_cornell(pkg, lib, core, orc, scenes, materials):
+    st, osc = _setup(pkg, lib, core, orc, scenes.cornell_box(materials), scenes.cornell_camera(), 96, 80, total_spp=3, seed=11)
+    r = osc.renderer(st, threads=8, counter_rng=True)
+    prev_g = prev_o = 0
+    for k in range(3):
+        core.render_passes(1); r.render_passes(1)
+        g, spp, _ = core.film(); o, ospp, _ = r.film()
+        assert spp == ospp == k + 1
+        _assert_films_match(g - prev_g, o - prev_o, f"sample {k + 1}")
+        prev_g, prev_o = g, o
+    assert (g > 0).any()
+
+
+def test_path_trace_per_sample_parity_env_mis(pkg, lib, core, orc, scenes):
+    """Every BSDF + environment-map importance sampling + MIS (use_mis on and off)."""
+    scene = scenes.mixed_scene(32, (128, 64))
+    for mis in (1, 0):
+        st, osc = _setup(pkg, lib, core, orc, scene, scenes.mixed_camera(), 128, 72, total_spp=2, seed=5, use_mis=mis)
+        r = osc.renderer(st, threads=8, counter_rng=True)
+        core.render_passes(2); r.render_passes(2)
+        g, _, _ = core.film(); o, _, _ = r.film()
+        _assert_films_match(g, o, f"env scene mis={mis}", frac=0.01)
+        assert g.mean() > 0.01
+
+
+def test_max_bounces_zero_and_no_light_hits(pkg, lib, core, orc, scenes):
+    for mb, chl in ((0, 1), (1, 0), (2, 1)):
+        st, osc = _setup(pkg, lib, core, orc, scenes.cornell_box("mixed"), scenes.cornell_camera(), 64, 64,
+                         total_spp=1, seed=3, max_bounces=mb, can_hit_light=chl)
+        r = osc.renderer(st, threads=4, counter_rng=True)
+        core.render_passes(1); r.render_passes(1)
+        _assert_films_match(core.film()[0], r.film()[0], f"max_bounces={mb} can_hit_light={chl}")
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])   # DM_NORMALS, DM_ALBEDO, DM_DIRECT
+def test_draw_modes(pkg, lib, core, orc, scenes, mode):
+    st, osc = _setup(pkg, lib, core, orc, scenes.cornell_box("mixed"), scenes.cornell_camera(), 80, 64, total_spp=2, seed=2, draw_mode=mode)
+    r = osc.renderer(st, threads=4, counter_rng=True)
+    core.render_passes(2); r.render_passes(2)
+    _assert_films_match(core.film()[0], r.film()[0], f"draw mode {mode}")
+
+
+def test_light_trace_parity(pkg, lib, core, orc, scenes):
+    """Light tracing splats land anywhere (float atomics on the GPU, one thread in the
+    oracle): compare the films pixel-wise with a tolerance scaled by the film's magnitude."""
+    st, osc = _setup(pkg, lib, core, orc, scenes.cornell_box("mixed"), scenes.cornell_camera(), 64, 64,
+                     algorithm=pkg.AL_LIGHT_TRACE, total_spp=4, seed=9)
+    r = osc.renderer(st, threads=1, counter_rng=True)
+    core.render_passes(4); r.render_passes(4)
+    g, spp, _ = core.film(); o, ospp, _ = r.film()
+    assert spp == ospp == 4 and o.sum() > 0
+    scale = np.abs(o).max()
+    bad = (np.abs(g - o) > 1e-4 * scale + 1e-4 * np.abs(o)).any(-1)
+    assert bad.mean() <= 0.01, f"{bad.mean():.4%} of pixels differ"
+    assert abs(g.sum() - o.sum()) <= 2e-3 * abs(o.sum())
+
+
+def test_instant_radiosity_parity(pkg, lib, core, orc, scenes):
+    st, osc = _setup(pkg, lib, core, orc, scenes.cornell_box("mixed"), scenes.cornell_camera(), 64, 48,
+                     algorithm=pkg.AL_INSTANT_RADIOSITY, total_spp=2, seed=4, num_threads=4, vpl_rays_per_tile=3)
+    r = osc.renderer(st, threads=4, counter_rng=True)
+    core.render_passes(2); r.render_passes(2)
+    assert len(r.vpls()) >= 12
+    _assert_films_match(core.film()[0], r.film()[0], "instant radiosity", frac=0.02)
+
+
+def test_gaussian_and_mitchell_filters(pkg, lib, core, orc, scenes):
+    for flt in (pkg.FT_GAUSSIAN, pkg.FT_MITCHELL_NETRAVALI):
+        st, osc = _setup(pkg, lib, core, orc, scenes.cornell_box("diffuse"), scenes.cornell_camera(), 48, 48, total_spp=1, seed=6, filter=flt)
+        r = osc.renderer(st, threads=1, counter_rng=True)
+        core.render_passes(1); r.render_passes(1)
+        g, o = core.film()[0], r.film()[0]
+        scale = np.abs(o).max()
+        assert (np.abs(g - o) <= 2e-4 * scale + 1e-4 * np.abs(o)).all(-1).mean() >= 0.99
+
+
+def test_adaptive_sampling_tile_targets(pkg, lib, core, orc, scenes):
+    """calculateTileSamples (RTBase/Renderer.h:643-671): on an identical film the targets
+    must be identical integers; in a full adaptive run they may differ by one where the
+    films differ in the last bits."""
+    st, osc = _setup(pkg, lib, core, orc, scenes.cornell_box("mixed"), scenes.cornell_camera(), 100, 70,
+                     total_spp=24, init_spp=4, adaptive_sampling=1, seed=8)
+    r = osc.renderer(st, threads=8, counter_rng=True)
+    rs = np.random.RandomState(0)
+    film = (rs.gamma(0.7, 2.0, (70, 100, 3)) * rs.uniform(0, 3, (70, 100, 1))).astype(np.float32)
+    r.film_write(film, 4); r.calculate_tile_samples()
+    core.film_write(film, 4); core.update_tile_samples()
+    assert np.array_equal(core.film()[2], r.film()[2])
+    # full run: skipping tiles after init_spp
+    core.clear(); r.clear()
+    core.render_passes(10); r.render_passes(10)
+    g, spp, gt = core.film(); o, ospp, ot = r.film()
+    assert spp == ospp == 10
+    assert (np.abs(gt.astype(np.int64) - ot.astype(np.int64)) <= 1).all() and (gt != ot).mean() <= 0.1
+    assert gt.min() >= 4 and gt.max() <= 24 and len(np.unique(gt)) > 3
+    same = np.repeat(np.repeat((gt == ot).reshape(5, 7), 16, 0), 16, 1)[:70, :100]
+    _assert_films_match(g * same[..., None], o * same[..., None], "adaptive film", frac=0.01)
+
+
+def test_tile_sharding_is_bit_identical_and_spp_split_sums(pkg, lib, core, orc, scenes):
+    """shard_mode 1: the union of the ranks' films is bit-identical to the single-GPU film;
+    shard_mode 2: the sum over ranks equals the single-GPU film of world*passes samples."""
+    scene, cam_kw = scenes.cornell_box("mixed"), scenes.cornell_camera()
+    _setup(pkg, lib, core, orc, scene, cam_kw, 80, 64, total_spp=4, seed=13)
+    core.render_passes(4)
+    full = core.film()[0]
+    acc = np.zeros_like(full)
+    for rank in range(3):
+        _setup(pkg, lib, core, orc, scene, cam_kw, 80, 64, total_spp=4, seed=13, shard_mode=1, shard_rank=rank, shard_world=3)
+        core.render_passes(4)
+        part = core.film()[0]
+        assert ((part != 0).any(-1) & (acc != 0).any(-1)).sum() == 0   # disjoint pixels
+        acc += part
+    assert np.array_equal(acc, full)
+    acc = np.zeros_like(full)
+    for rank in range(2):
+        _setup(pkg, lib, core, orc, scene, cam_kw, 80, 64, total_spp=4, seed=13, shard_mode=2, shard_rank=rank, shard_world=2)
+        core.render_passes(2)
+        acc += core.film()[0]
+    assert np.allclose(acc, full, rtol=1e-5, atol=1e-6)
+
+
+def test_converged_radiance_vs_reference_streams(pkg, lib, core, orc, scenes):
+    """Statistical parity at high spp against the oracle driven by the reference's own
+    per-thread MT19937 streams. Tolerance: relative RMSE of the 4x4-binned images <= 5 %,
+    mean radiance within 2 %."""
+    spp = 192
+    st, osc = _setup(pkg, lib, core, orc, scenes.cornell_box("mixed"), scenes.cornell_camera(), 64, 64, total_spp=spp, seed=21)
+    r = osc.renderer(st, threads=16, counter_rng=False)
+    core.render_passes(spp); r.render_passes(spp)
+    g = np.clip(core.film()[0] / spp, 0, 4).reshape(16, 4, 16, 4, 3).mean((1, 3))
+    o = np.clip(r.film()[0] / spp, 0, 4).reshape(16, 4, 16, 4, 3).mean((1, 3))
+    rel_rmse = np.sqrt(((g - o) ** 2).mean()) / o.mean()
+    assert rel_rmse <= 0.05, rel_rmse
+    assert abs(g.mean() - o.mean()) <= 0.02 * o.mean()
