@@ -174,6 +174,35 @@ void orc_calculate_tile_samples(orc_renderer* r) { r->r.calculateTileSamples(); 
 // Film::splat (Imaging.h:318-340) of n samples (x, y, r, g, b) in order
 void orc_film_splat(orc_renderer* r, const float* xyrgb, size_t n) { for (size_t i = 0; i < n; i++) r->r.film.splat(xyrgb[5 * i], xyrgb[5 * i + 1], rgb(xyrgb[5 * i + 2], xyrgb[5 * i + 3], xyrgb[5 * i + 4])); }
 
+// ---- the oracle's math / sampling layer, entry by entry as oracle/ref_core.cpp exposes the
+// real RTBase/Core.h + RTBase/Sampling.h (same signatures, so tests can diff them) ----------
+static M4 m4(const float* m) { M4 a; std::memcpy(a.m, m, 64); return a; }
+static void put3(float* o, V3 v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
+void orc_matrix_invert(const float* m, float* out) { M4 r = invert(m4(m)); std::memcpy(out, r.m, 64); }
+void orc_look_at(const float* f, const float* t, const float* u, float* out) { M4 r = lookAt(v3(f[0], f[1], f[2]), v3(t[0], t[1], t[2]), v3(u[0], u[1], u[2])); std::memcpy(out, r.m, 64); }
+void orc_perspective(float n, float f, float aspect, float fov, float* out) { M4 r = perspective(n, f, aspect, fov); std::memcpy(out, r.m, 64); }
+void orc_mul_point(const float* m, const float* v, float* out) { put3(out, mulPoint(m4(m), v3(v[0], v[1], v[2]))); }
+void orc_mul_vec(const float* m, const float* v, float* out) { put3(out, mulVec(m4(m), v3(v[0], v[1], v[2]))); }
+void orc_mul_point_divide(const float* m, const float* v, float* out) { put3(out, mulPointDivide(m4(m), v3(v[0], v[1], v[2]))); }
+float orc_lum(const float* c) { return lum(rgb(c[0], c[1], c[2])); }
+void orc_frame(const float* n, const float* vec, float* out)
+{
+    Frame f; f.fromVector(v3(n[0], n[1], n[2])); V3 a = v3(vec[0], vec[1], vec[2]);
+    put3(out, f.u); put3(out + 3, f.v); put3(out + 6, f.w); put3(out + 9, f.toLocal(a)); put3(out + 12, f.toWorld(a));
+}
+void orc_warp(int kind, float r1, float r2, float* out)
+{
+    V3 d; float pdf;
+    if (kind == 0) { d = cosineSampleHemisphere(r1, r2); pdf = cosineHemispherePDF(d); }
+    else if (kind == 1) { d = uniformSampleSphere(r1, r2); pdf = uniformSpherePDF(); }
+    else {   // uniformSampleHemisphere / uniformHemispherePDF, Sampling.h:35-46
+        float cosTheta = r1; float sinTheta = sqrtf(1.0f - cosTheta * cosTheta); float phi = (float)(2.0f * kPi * r2);
+        d = v3(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta); pdf = (float)(fabsf(d.z) / (2.0f * kPi));
+    }
+    put3(out, d); out[3] = pdf;
+}
+void orc_mt_stream(unsigned seed, int n, float* out) { MTSampler s(seed); for (int i = 0; i < n; i++) out[i] = s.next(); }
+
 // the counter sampler itself, for checking the device generator
 float orc_rng(uint32_t seed, uint32_t stream, uint32_t item, uint32_t sample, uint32_t dim) { return rtx_rng_float(rtx_rng_key(seed, stream, item, sample), dim); }
 

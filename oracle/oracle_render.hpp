@@ -832,7 +832,9 @@ struct Renderer {
                 for (unsigned y = sy; y < ey; y++) for (unsigned x = sx; x < ex; x++) {
                     if (counterRng) {
                         uint32_t stream = st.algorithm == RTX_AL_LIGHT_TRACE && st.draw_mode == RTX_DM_ALGORITHM ? RTX_STREAM_LIGHT : RTX_STREAM_CAMERA;
-                        cs.reset(st.seed, stream, y * film.width + x, (uint32_t)film.SPP);
+                        // shard_mode 2: this rank renders global sample indices rank+1, rank+1+world, ...
+                        uint32_t sample = (st.shard_mode == 2 && st.shard_world > 1) ? (uint32_t)(film.SPP - 1) * (uint32_t)st.shard_world + (uint32_t)st.shard_rank + 1u : (uint32_t)film.SPP;
+                        cs.reset(st.seed, stream, y * film.width + x, sample);
                         pixel(x, y, &cs);
                     } else pixel(x, y, &mt[id]);
                 }
@@ -842,7 +844,7 @@ struct Renderer {
         unsigned nt = (st.algorithm == RTX_AL_LIGHT_TRACE && st.draw_mode == RTX_DM_ALGORITHM) || film.filter != RTX_FT_BOX ? 1 : numThreads;
         if (nt <= 1) work(0);
         else { std::vector<std::thread> th; for (unsigned i = 0; i < nt; i++) th.emplace_back(work, i); for (auto& t : th) t.join(); }
-        if (film.SPP == (int)st.init_spp && st.algorithm != RTX_AL_LIGHT_TRACE) calculateTileSamples();
+        if (film.SPP == (int)st.init_spp && st.algorithm != RTX_AL_LIGHT_TRACE && st.shard_mode != 2) calculateTileSamples();
     }
 };
 

@@ -78,8 +78,10 @@ __device__ __forceinline__ void slot_pixel(uint32_t slot, uint32_t tiles_x, uint
 __device__ __forceinline__ bool tile_active(const WfPtrs& w, const PassParams& pp, uint32_t tile)
 {
     const rtx_settings& s = pp.st;
-    // processTile's skip, RTBase/Renderer.h:682-687
-    if (pp.spp > (int)s.init_spp && pp.spp > (int)w.tile_samples[tile] && s.algorithm != RTX_AL_LIGHT_TRACE) return false;
+    // processTile's skip, RTBase/Renderer.h:682-687; with the sample split across GPUs the
+    // count that matters is the global sample index this pass renders
+    const int cur = s.shard_mode == 2 ? (int)pp.sample_index : pp.spp;
+    if (cur > (int)s.init_spp && cur > (int)w.tile_samples[tile] && s.algorithm != RTX_AL_LIGHT_TRACE) return false;
     if (s.shard_mode == 1 && s.shard_world > 1 && (int)(tile % (uint32_t)s.shard_world) != s.shard_rank) return false;
     return true;
 }

@@ -171,14 +171,25 @@ def test_tile_sharding_is_bit_identical_and_spp_split_sums(pkg, lib, core, orc, 
 
 def test_converged_radiance_vs_reference_streams(pkg, lib, core, orc, scenes):
     """Statistical parity at high spp against the oracle driven by the reference's own
-    per-thread MT19937 streams. Tolerance: relative RMSE of the 4x4-binned images <= 5 %,
-    mean radiance within 2 %."""
-    spp = 192
-    st, osc = _setup(pkg, lib, core, orc, scenes.cornell_box("mixed"), scenes.cornell_camera(), 64, 64, total_spp=spp, seed=21)
+    per-thread MT19937 streams (independent randomness). The noise floor is measured, not
+    guessed: two GPU renders with different seeds give the RMSE that pure Monte-Carlo noise
+    produces at this spp; the GPU-vs-oracle RMSE (8x8-binned, radiance clipped at 4) must
+    stay within 1.5x that floor + 0.5 % of the mean, and the mean radiance within 1.5 %."""
+    spp = 768
+
+    def binned(film):
+        return np.clip(film / spp, 0, 4).reshape(8, 8, 8, 8, 3).mean((1, 3))
+
+    scene, cam_kw = scenes.cornell_box("mixed"), scenes.cornell_camera()
+    imgs = []
+    for seed in (21, 22):
+        st, osc = _setup(pkg, lib, core, orc, scene, cam_kw, 64, 64, total_spp=spp, seed=seed)
+        core.render_passes(spp)
+        imgs.append(binned(core.film()[0]))
     r = osc.renderer(st, threads=16, counter_rng=False)
-    core.render_passes(spp); r.render_passes(spp)
-    g = np.clip(core.film()[0] / spp, 0, 4).reshape(16, 4, 16, 4, 3).mean((1, 3))
-    o = np.clip(r.film()[0] / spp, 0, 4).reshape(16, 4, 16, 4, 3).mean((1, 3))
-    rel_rmse = np.sqrt(((g - o) ** 2).mean()) / o.mean()
-    assert rel_rmse <= 0.05, rel_rmse
-    assert abs(g.mean() - o.mean()) <= 0.02 * o.mean()
+    r.render_passes(spp)
+    o = binned(r.film()[0])
+    rmse = lambda a, b: float(np.sqrt(((a - b) ** 2).mean()))
+    floor = rmse(imgs[0], imgs[1])
+    assert rmse(imgs[0], o) <= 1.5 * floor + 0.005 * o.mean(), (rmse(imgs[0], o), floor, o.mean())
+    assert abs(imgs[0].mean() - o.mean()) <= 0.015 * o.mean()

@@ -1,0 +1,88 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol
+include/rtx.h declares, the host BVH build reproduces the reference tree node for node, the
+camera set-up and the counter RNG agree with the oracle. No compute call needs a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "rtx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(rtx_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 30
+    for n in sorted(names):
+        assert hasattr(lib, n), f"librtx.so does not export {n}"
+
+
+def test_errors_are_reported_without_a_gpu_call(pkg, lib, scenes):
+    sc = scenes.cornell_box()
+    sc.desc.n_materials = 0
+    h = C.c_void_p()
+    assert lib.rtx_host_bvh_build(C.byref(sc.desc), C.byref(h)) == -1          # RTX_ERR_INVALID
+    assert b"no materials" in lib.rtx_last_error()
+    assert lib.rtx_camera_look_at(None, None, None, None, 45.0, 4, 4, 0) == -1
+    cam = pkg.Camera()
+    v = (C.c_float * 3)(0, 0, 1)
+    assert lib.rtx_camera_look_at(C.byref(cam), v, v, v, 45.0, 0, 4, 0) == -1
+    assert lib.rtx_get_spp(None, None) == -1
+
+
+@pytest.mark.parametrize("name", ["soup", "soup_big_tris", "cornell", "mixed", "duplicates", "tiny"])
+def test_host_bvh_equals_reference_restatement(pkg, lib, orc, scenes, name):
+    if name == "soup":
+        sc = scenes.soup(30000, seed=5)
+    elif name == "soup_big_tris":
+        sc = scenes.soup(5000, seed=6, size=0.4)
+    elif name == "cornell":
+        sc = scenes.cornell_box("mixed")
+    elif name == "mixed":
+        sc = scenes.mixed_scene(24, (32, 16))
+    elif name == "tiny":
+        sc = scenes.soup(5, seed=1, size=0.5)
+    else:
+        base = scenes.soup(40, seed=5, size=0.2)
+        P = np.tile(base.positions[:4], (30, 1, 1))     # 120 coincident triangles: unsplittable leaves
+        sc = pkg.SceneArrays(P, np.tile(base.normals[:4], (30, 1, 1)), np.tile(base.uvs[:4], (30, 1, 1)),
+                             np.zeros(len(P), np.uint32), base.materials, base.textures)
+    b, t, i, d, wn, wd = pkg.host_bvh(lib, sc)
+    ob, ot, oi, od = orc.scene(sc).bvh()
+    assert d == od
+    assert np.array_equal(t, ot), "node ranges / children differ"
+    assert np.array_equal(i, oi), "triangle permutation differs"
+    assert np.array_equal(b, ob), "node bounds differ"
+    assert 1 <= wn <= len(t) and wd >= 1
+
+
+def test_camera_set_up_equals_oracle_bit_for_bit(pkg, lib, orc):
+    for frm, to, up, fov, w, h, flip in (((0, 0, 3.5), (0, 0, 0), (0, 1, 0), 45.0, 1920, 1080, 0),
+                                         ((0, 2.2, 7.5), (0, 0.8, 0), (0, 1, 0), 40.0, 640, 360, 1),
+                                         ((3, 4, -5), (0.5, 0.25, 0.125), (0.1, 0.9, 0.2), 60.0, 333, 77, 0)):
+        a = pkg.look_at(lib, frm, to, up, fov, w, h, flip)
+        b = orc.look_at(frm, to, up, fov, w, h, flip)
+        for f in ("proj", "inv_proj", "camera", "camera_to_view", "origin", "view_dir"):
+            assert np.array_equal(np.array(getattr(a, f)), np.array(getattr(b, f))), f
+        assert a.afilm == b.afilm and (a.width, a.height) == (b.width, b.height) == (w, h)
+
+
+def test_counter_rng_known_values(orc):
+    """The generator is a definition (include/rtx_rng.h); these values pin it."""
+    got = [orc.lib.orc_rng(*a) for a in ((1, 0, 0, 1, 0), (1, 0, 0, 1, 1), (7, 1, 12345, 3, 9), (0xFFFFFFFF, 2, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF))]
+    assert all(1e-8 <= g < 1.0 for g in got)
+    assert len(set(got)) == 4
+    vals = np.array([orc.lib.orc_rng(3, 0, i, 1, d) for i in range(64) for d in range(32)])
+    assert abs(vals.mean() - 0.5) < 0.03 and abs(np.var(vals) - 1 / 12) < 0.01
+
+
+def test_scene_generators_are_deterministic(scenes):
+    a, b = scenes.soup(1000, seed=9), scenes.soup(1000, seed=9)
+    assert np.array_equal(a.positions, b.positions)
+    box = scenes.cornell_box("mixed")
+    assert box.n_triangles == 48 and len(box.materials) == 8
+    m = scenes.mixed_scene(16, (32, 16))
+    assert m.env.shape == (16, 32, 3) and m.n_triangles > 8000
