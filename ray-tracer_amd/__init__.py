@@ -117,6 +117,27 @@ class SceneArrays:
     def n_triangles(self):
         return self.positions.shape[0]
 
+    def save(self, path, frm, to, up, fov, width, height):
+        """Write the scene + camera as an .rtxs dump for the headless C++ driver
+        (ray-tracer_amd/host/main.cpp documents the layout)."""
+        import struct
+        with open(path, "wb") as f:
+            f.write(b"RTXS" + struct.pack("<I", 1))
+            f.write(struct.pack("<10f2I", *frm, *to, *up, fov, width, height))
+            f.write(struct.pack("<I", len(self.textures)))
+            for t in self.textures:
+                f.write(struct.pack("<2I", t.shape[1], t.shape[0]) + t.tobytes())
+            f.write(struct.pack("<I", len(self.materials)))
+            for m in self.materials:
+                f.write(bytes(m))
+            f.write(struct.pack("<Q", self.n_triangles))
+            f.write(self.positions.tobytes() + self.normals.tobytes() + self.uvs.tobytes() + self.material_index.tobytes())
+            if self.env is not None:
+                f.write(struct.pack("<2I", self.env.shape[1], self.env.shape[0]) + self.env.tobytes())
+            else:
+                f.write(struct.pack("<2I", 0, 0))
+            f.write(struct.pack("<3f", *self.desc.background))
+
 
 def material(type=BSDF_DIFFUSE, texture=0, emission=(0, 0, 0), eta=(0, 0, 0), k=(0, 0, 0), roughness=1.0,
              int_ior=1.33, ext_ior=1.0) -> Material:
