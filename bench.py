@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pathtrace", action="store_true")
     ap.add_argument("--pt-spp", type=int, default=16, help="passes of the path-trace side measurement")
+    ap.add_argument("--variants", default="", help="A/B: comma list of RTX_VARIANT values, interleaved rounds in one process")
     args = ap.parse_args()
 
     import torch
@@ -71,6 +72,10 @@ def main():
     pixel = torch.empty(n, dtype=torch.int32, device=dev)
     core.generate_primary_rays_device(rays.data_ptr(), pixel.data_ptr(), n)
     torch.cuda.synchronize()
+
+    if args.variants:
+        ab_variants(pkg, lib, scene, cam, args, rays, hits, n, torch, local_rank)
+        return
 
     def barrier():
         if world > 1:
@@ -129,6 +134,36 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def ab_variants(pkg, lib, scene, cam, args, rays, hits, n, torch, local_rank):
+    """Interleaved rounds of the closest-hit kernel under different RTX_VARIANT schedules
+    (one context each, same rays), median and min kernel ms per variant."""
+    cores = {}
+    for v in [int(x) for x in args.variants.split(",")]:
+        os.environ["RTX_VARIANT"] = str(v)
+        c = pkg.Core(local_rank, lib)
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        c.upload_scene(scene); c.set_camera(cam)
+        cores[v] = c
+    ref = None
+    times = {v: [] for v in cores}
+    for rnd in range(7):
+        for v, c in cores.items():
+            c.trace_closest_device(rays.data_ptr(), n, hits.data_ptr())
+            torch.cuda.synchronize()
+            c.timer_begin()
+            for _ in range(args.steps):
+                c.trace_closest_device(rays.data_ptr(), n, hits.data_ptr())
+            times[v].append(c.timer_end() / args.steps)
+            h = hits.clone()
+            if ref is None:
+                ref = h
+            assert torch.equal(h, ref), f"variant {v} changes the hits"
+    for v, t in times.items():
+        t = sorted(t)
+        print(json.dumps({"variant": v, "median_ms": round(t[len(t) // 2], 4), "min_ms": round(t[0], 4),
+                          "mrays_per_s_median": round(n / t[len(t) // 2] / 1e3, 1)}))
 
 
 def cpu_baseline(pkg, scene, cam, args):

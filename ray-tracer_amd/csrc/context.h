@@ -13,6 +13,7 @@ namespace rtx {
 
 constexpr int kBlock = 256;        // threads per workgroup (4 waves)
 constexpr int kLdsStack = 12;      // traversal-stack entries per lane kept in LDS
+constexpr int kMinLdsStack = 4;    // smallest LDS part of any kernel variant (sizes the global spill slab)
 constexpr int kMaxGridBlocks = 2048;   // 256 CUs x 8 resident workgroups
 
 // Device buffer that frees itself.
@@ -30,6 +31,7 @@ struct WavefrontBuffers;   // path-tracing state (wavefront.h)
 
 struct rtx_ctx {
     int device = 0;
+    int variant = 0;               // traversal schedule under test (RTX_VARIANT), 0 = default
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 

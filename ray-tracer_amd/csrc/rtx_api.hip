@@ -59,11 +59,13 @@ int rtx_create(rtx_ctx** out, int device)
     rtx_ctx* c = new (std::nothrow) rtx_ctx;
     if (!c) return fail(RTX_ERR_NOMEM, "out of host memory");
     c->device = device;
+    c->variant = 1;
+    if (const char* v = getenv("RTX_VARIANT")) c->variant = atoi(v);
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
-    HIP_TRY(c->b_counters.ensure(64));
+    HIP_TRY(c->b_counters.ensure(256));
     // RayTracer's defaults, RTBase/Settings.h:40-61
     rtx_settings& s = c->settings;
     s.algorithm = RTX_AL_PATH_TRACE; s.draw_mode = RTX_DM_ALGORITHM; s.filter = RTX_FT_BOX;
@@ -132,7 +134,8 @@ int rtx_upload_scene(rtx_ctx* c, const rtx_scene_desc* d)
     // traversal stack: at most three pushes per wide level, or one pending node per binary
     // level on the exact path; entries beyond the LDS part go to global memory
     uint32_t need = std::max(3u * h.bvh4.depth + 2u, h.bvh2.depth + 3u);
-    c->spill_entries = need > (uint32_t)kLdsStack ? need - kLdsStack : 0;
+    // (sized for the shallowest LDS part any kernel variant uses)
+    c->spill_entries = need > (uint32_t)kMinLdsStack ? need - kMinLdsStack : 0;
     if ((rc = ensure_spill(c))) return rc;
 
     c->stats.bvh2_nodes = (uint32_t)h.bvh2.nodes.size(); c->stats.bvh2_depth = h.bvh2.depth;
@@ -273,8 +276,17 @@ int rtx_trace_closest_device(rtx_ctx* c, const rtx_ray* rays, size_t n, rtx_hit*
     if (n == 0) return RTX_OK;
     if (!rays || !hits) return fail(RTX_ERR_INVALID, "null buffer");
     if (n > 0xFFFFFFFFull) return fail(RTX_ERR_INVALID, "too many rays in one call");
-    hipLaunchKernelGGL(k_closest<false>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, c->dscene, rays, (const uint32_t*)nullptr,
-                       (uint32_t)n, hits, c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), (unsigned long long*)nullptr);
+    if (c->variant == 0) {
+        // A/B baseline: static assignment of rays to lanes (RTX_VARIANT=0)
+        hipLaunchKernelGGL(k_closest_static, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, c->dscene, rays, (uint32_t)n, hits,
+                           c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock));
+    } else {
+        uint32_t* wc = c->b_counters.as<uint32_t>() + 32;
+        HIP_TRY(hipMemsetAsync(wc, 0, 4, c->stream));
+        hipLaunchKernelGGL(k_closest<false>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, c->dscene, rays, (const uint32_t*)nullptr,
+                           (uint32_t)n, (const uint32_t*)nullptr, hits, c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), wc,
+                           (unsigned long long*)nullptr);
+    }
     HIP_TRY(hipGetLastError());
     c->stats.closest_rays += n;
     return RTX_OK;
@@ -302,8 +314,10 @@ int rtx_trace_visible_device(rtx_ctx* c, const float* p1p2, size_t n, uint8_t* v
     if (n == 0) return RTX_OK;
     if (!p1p2 || !vis) return fail(RTX_ERR_INVALID, "null buffer");
     if (n > 0xFFFFFFFFull) return fail(RTX_ERR_INVALID, "too many segments in one call");
+    uint32_t* wc = c->b_counters.as<uint32_t>() + 33;
+    HIP_TRY(hipMemsetAsync(wc, 0, 4, c->stream));
     hipLaunchKernelGGL(k_visible, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, c->dscene, p1p2, (uint32_t)n, vis,
-                       c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock));
+                       c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), wc);
     HIP_TRY(hipGetLastError());
     c->stats.shadow_rays += n;
     return RTX_OK;
@@ -342,14 +356,16 @@ int rtx_count_closest_work(rtx_ctx* c, const rtx_ray* rays, size_t n, uint64_t* 
     if (!c->have_scene) return fail(RTX_ERR_STATE, "no scene uploaded");
     if (!rays || !nodes || !tris || n == 0 || n > 0xFFFFFFFFull) return fail(RTX_ERR_INVALID, "bad argument");
     HIP_TRY(c->b_io_b.ensure(n * sizeof(rtx_hit)));
-    HIP_TRY(hipMemsetAsync(c->b_counters.p, 0, 16, c->stream));
+    HIP_TRY(hipMemsetAsync(c->b_counters.p, 0, 256, c->stream));
     hipLaunchKernelGGL(k_closest<true>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, c->dscene, rays, (const uint32_t*)nullptr,
-                       (uint32_t)n, c->b_io_b.as<rtx_hit>(), c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock),
-                       c->b_counters.as<unsigned long long>());
+                       (uint32_t)n, (const uint32_t*)nullptr, c->b_io_b.as<rtx_hit>(), c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock),
+                       c->b_counters.as<uint32_t>() + 32, c->b_counters.as<unsigned long long>());
     HIP_TRY(hipGetLastError());
-    unsigned long long h[2];
-    HIP_TRY(hipMemcpyAsync(h, c->b_counters.p, 16, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long h[5];
+    HIP_TRY(hipMemcpyAsync(h, c->b_counters.p, 40, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (getenv("RTX_DEBUG_COUNTERS"))
+        fprintf(stderr, "[rtx] lane node visits %llu, lane tri tests %llu; wave inner trips %llu, wave tri trips %llu, wave outer trips %llu\n", h[0], h[1], h[2], h[3], h[4]);
     *nodes = h[0]; *tris = h[1];
     return RTX_OK;
 }

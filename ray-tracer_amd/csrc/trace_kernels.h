@@ -3,10 +3,13 @@
 
 #include "context.h"
 #include "traverse.h"
+#include "traverse_dyn.h"
 
 namespace rtx {
 
 constexpr float kEpsilon = 0.001f;    // EPSILON, RTBase/Geometry.h:54
+constexpr int kRefill = 32;           // idle lanes that trigger a fetch of new rays
+constexpr int kTriUnroll = 4;         // leaf triangles whose loads are issued together
 
 __device__ __forceinline__ uint32_t global_thread() { return blockIdx.x * kBlock + threadIdx.x; }
 
@@ -29,77 +32,83 @@ __device__ __forceinline__ void camera_ray(const CameraDev& c, float x, float y,
     dx = wx * l; dy = wy * l; dz = wz * l;
 }
 
-// Closest hit for rays[queue ? queue[i] : i], i < n. One ray per lane, grid-stride.
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_closest(DeviceScene sc, const rtx_ray* __restrict__ rays, const uint32_t* __restrict__ queue,
-                                                    uint32_t n, rtx_hit* __restrict__ hits, uint2* spill, uint32_t spill_stride,
-                                                    unsigned long long* counters)
+__device__ __forceinline__ rtx_hit make_hit(const DeviceScene& sc, const HitRec& best)
 {
-    __shared__ uint2 lds[kBlock * kLdsStack];
-    LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
-    TravCount cnt{0, 0};
-    for (uint32_t i = global_thread(); i < n; i += gridDim.x * kBlock) {
-        const uint32_t idx = queue ? queue[i] : i;
-        const rtx_ray r = rays[idx];
-        HitRec best;
-        traverse<false, COUNT, kBlock, kLdsStack>(sc, stk, r.o[0], r.o[1], r.o[2], r.d[0], r.d[1], r.d[2], 0.0f, best, &cnt);
-        rtx_hit h;
-        if (best.pos != 0xFFFFFFFFu) {
-            h.id = __float_as_uint(sc.tris[best.pos].q0.w);
-            h.t = best.t; h.alpha = best.u; h.beta = best.v; h.gamma = 1.0f - (best.u + best.v);   // Geometry.h:537-541
-        } else { h.id = 0xFFFFFFFFu; h.t = FLT_MAX; h.alpha = 0; h.beta = 0; h.gamma = 0; }
-        hits[idx] = h;
-    }
-    if (COUNT) { atomicAdd(&counters[0], (unsigned long long)cnt.nodes); atomicAdd(&counters[1], (unsigned long long)cnt.tris); }
+    rtx_hit h;
+    if (best.pos != 0xFFFFFFFFu) {
+        h.id = __float_as_uint(sc.tris[best.pos].q0.w);
+        h.t = best.t; h.alpha = best.u; h.beta = best.v; h.gamma = 1.0f - (best.u + best.v);   // Geometry.h:537-541
+    } else { h.id = 0xFFFFFFFFu; h.t = FLT_MAX; h.alpha = 0; h.beta = 0; h.gamma = 0; }
+    return h;
 }
 
-// Closest hit for the live paths of a wavefront stage: rays[queue[i]], i < *n_dev (the
-// queue length stays on the device).
-__global__ __launch_bounds__(kBlock) void k_closest_q(DeviceScene sc, const rtx_ray* __restrict__ rays, const uint32_t* __restrict__ queue,
-                                                      const uint32_t* __restrict__ n_dev, rtx_hit* __restrict__ hits, uint2* spill, uint32_t spill_stride)
+// Reference schedule: one ray per lane, grid-stride, each wave finishes its 64 rays before
+// taking the next 64. Kept as the A/B baseline of the dynamic schedule (RTX_VARIANT=0).
+__global__ __launch_bounds__(kBlock) void k_closest_static(DeviceScene sc, const rtx_ray* __restrict__ rays, uint32_t n, rtx_hit* __restrict__ hits,
+                                                           uint2* spill, uint32_t spill_stride)
 {
     __shared__ uint2 lds[kBlock * kLdsStack];
     LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
-    const uint32_t n = *n_dev;
     for (uint32_t i = global_thread(); i < n; i += gridDim.x * kBlock) {
-        const uint32_t idx = queue[i];
-        const rtx_ray r = rays[idx];
+        const rtx_ray r = rays[i];
         HitRec best;
         traverse<false, false, kBlock, kLdsStack>(sc, stk, r.o[0], r.o[1], r.o[2], r.d[0], r.d[1], r.d[2], 0.0f, best, nullptr);
-        rtx_hit h;
-        if (best.pos != 0xFFFFFFFFu) {
-            h.id = __float_as_uint(sc.tris[best.pos].q0.w);
-            h.t = best.t; h.alpha = best.u; h.beta = best.v; h.gamma = 1.0f - (best.u + best.v);
-        } else { h.id = 0xFFFFFFFFu; h.t = FLT_MAX; h.alpha = 0; h.beta = 0; h.gamma = 0; }
-        hits[idx] = h;
+        hits[i] = make_hit(sc, best);
     }
 }
 
-// Scene::visible, RTBase/Scene.h:170-178, for one segment
+// ---- closest hit: Scene::traverse, RTBase/Scene.h:137 -> BVHTree::traverse, Geometry.h:506-566 ----
+struct ClosestPolicy {
+    const DeviceScene& sc; const rtx_ray* rays; const uint32_t* queue; rtx_hit* hits;
+    __device__ __forceinline__ uint32_t index(uint32_t k) const { return queue ? queue[k] : k; }
+    __device__ __forceinline__ void fetch(uint32_t k, float o[3], float d[3], float& maxT) const
+    {
+        const rtx_ray r = rays[index(k)];
+        o[0] = r.o[0]; o[1] = r.o[1]; o[2] = r.o[2]; d[0] = r.d[0]; d[1] = r.d[1]; d[2] = r.d[2]; maxT = 0.0f;
+    }
+    __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool) const { hits[index(k)] = make_hit(sc, best); }
+};
+
+// rays[queue ? queue[i] : i] for i < (n_dev ? *n_dev : n_host); *work_counter must be 0 at launch
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_closest(DeviceScene sc, const rtx_ray* __restrict__ rays, const uint32_t* __restrict__ queue,
+                                                    uint32_t n_host, const uint32_t* __restrict__ n_dev, rtx_hit* __restrict__ hits,
+                                                    uint2* spill, uint32_t spill_stride, uint32_t* work_counter, unsigned long long* counters)
+{
+    __shared__ uint2 lds[kBlock * kLdsStack];
+    LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
+    ClosestPolicy pol{sc, rays, queue, hits};
+    traverse_dyn<ClosestPolicy, false, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll>(sc, stk, n_dev ? *n_dev : n_host, work_counter, pol, counters);
+}
+
+// ---- visibility: Scene::visible, RTBase/Scene.h:170-178 -> traverseVisible, Geometry.h:568-610 ----
+// A segment whose ray misses the root box is NOT visible (Geometry.h:571-572).
+struct VisiblePolicy {
+    const float* segments; uint8_t* visible;
+    __device__ __forceinline__ void fetch(uint32_t k, float o[3], float d[3], float& maxT) const { segment_to_ray(segments + (size_t)k * 6, o, d, maxT); }
+    __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool reached) const { visible[k] = (reached && best.pos == 0xFFFFFFFFu) ? 1 : 0; }
+};
+
+__global__ __launch_bounds__(kBlock) void k_visible(DeviceScene sc, const float* __restrict__ p1p2, uint32_t n, uint8_t* __restrict__ visible,
+                                                    uint2* spill, uint32_t spill_stride, uint32_t* work_counter)
+{
+    __shared__ uint2 lds[kBlock * kLdsStack];
+    LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
+    VisiblePolicy pol{p1p2, visible};
+    traverse_dyn<VisiblePolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll>(sc, stk, n, work_counter, pol, nullptr);
+}
+
+// One segment, inside a kernel that loops over segments per lane (the VPL gather)
 template <int BLOCK, int LDS_N>
 __device__ __forceinline__ bool segment_visible(const DeviceScene& sc, LaneStack<BLOCK, LDS_N>& stk,
                                                 float p1x, float p1y, float p1z, float p2x, float p2y, float p2z)
 {
-    float dx = p2x - p1x, dy = p2y - p1y, dz = p2z - p1z;
-    float len2 = (dx * dx) + (dy * dy) + (dz * dz);
-    float maxT = sqrtf(len2) - (2.0f * kEpsilon);
-    float l = 1.0f / sqrtf(len2);
-    dx = dx * l; dy = dy * l; dz = dz * l;
-    float ox = p1x + (dx * kEpsilon), oy = p1y + (dy * kEpsilon), oz = p1z + (dz * kEpsilon);
+    const float s[6] = {p1x, p1y, p1z, p2x, p2y, p2z};
+    float o[3], d[3], maxT;
+    segment_to_ray(s, o, d, maxT);
     HitRec best;
-    bool root = traverse<true, false, BLOCK, LDS_N>(sc, stk, ox, oy, oz, dx, dy, dz, maxT, best, nullptr);
+    bool root = traverse<true, false, BLOCK, LDS_N>(sc, stk, o[0], o[1], o[2], d[0], d[1], d[2], maxT, best, nullptr);
     return root && best.pos == 0xFFFFFFFFu;
-}
-
-__global__ __launch_bounds__(kBlock) void k_visible(DeviceScene sc, const float* __restrict__ p1p2, uint32_t n,
-                                                    uint8_t* __restrict__ visible, uint2* spill, uint32_t spill_stride)
-{
-    __shared__ uint2 lds[kBlock * kLdsStack];
-    LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
-    for (uint32_t i = global_thread(); i < n; i += gridDim.x * kBlock) {
-        const float* p = p1p2 + (size_t)i * 6;
-        visible[i] = segment_visible(sc, stk, p[0], p[1], p[2], p[3], p[4], p[5]) ? 1 : 0;
-    }
 }
 
 // Position of pixel (x, y) in the 8x8-tile ray order: whole tile rows above, whole tiles to

@@ -223,4 +223,92 @@ __device__ __forceinline__ bool traverse(const DeviceScene& sc, LaneStack<BLOCK,
     }
 }
 
+
+// ---- phase-batched traversal ("while-while") ------------------------------------------------
+// Same candidates, same result as traverse(); only the schedule differs: every lane keeps
+// descending inner nodes until it holds a leaf (or has finished), then the wave tests leaf
+// triangles together. On a 64-wide wave this keeps far more lanes busy than alternating
+// one node step and one leaf step per iteration.
+constexpr uint32_t kDone = kEmptySlot;
+
+template <int BLOCK, int LDS_N>
+__device__ __forceinline__ uint32_t pop_next(LaneStack<BLOCK, LDS_N>& stk, float bound)
+{
+    for (;;) {
+        if (stk.sp == 0) return kDone;
+        uint2 e = stk.pop();
+        if (!(__uint_as_float(e.y) > bound)) return e.x;
+    }
+}
+
+// One inner node: slab-test its four slots, push the far hits, return the nearest (or the
+// next pending subtree when nothing is hit).
+template <bool COUNT, int BLOCK, int LDS_N>
+__device__ __forceinline__ uint32_t step_inner(const DeviceScene& sc, LaneStack<BLOCK, LDS_N>& stk, uint32_t cur,
+                                               float ox, float oy, float oz, float ix, float iy, float iz, float bound, TravCount* cnt)
+{
+    const float4* np = sc.nodes4 + (size_t)cur * 8;
+    const float4 lox = np[0], loy = np[1], loz = np[2], hix = np[3], hiy = np[4], hiz = np[5];
+    const float4 cf = np[6];
+    if (COUNT) cnt->nodes++;
+    const uint32_t ref[4] = {__float_as_uint(cf.x), __float_as_uint(cf.y), __float_as_uint(cf.z), __float_as_uint(cf.w)};
+    const float lx[4] = {lox.x, lox.y, lox.z, lox.w}, ly[4] = {loy.x, loy.y, loy.z, loy.w}, lz[4] = {loz.x, loz.y, loz.z, loz.w};
+    const float hx[4] = {hix.x, hix.y, hix.z, hix.w}, hy[4] = {hiy.x, hiy.y, hiy.z, hiy.w}, hz[4] = {hiz.x, hiz.y, hiz.z, hiz.w};
+    float key[4]; uint32_t kref[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        float t0x = (lx[c] - ox) * ix, t1x = (hx[c] - ox) * ix;
+        float t0y = (ly[c] - oy) * iy, t1y = (hy[c] - oy) * iy;
+        float t0z = (lz[c] - oz) * iz, t1z = (hz[c] - oz) * iz;
+        float tentry = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+        float texit = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+        bool hit = !(tentry > texit || texit < 0) && (ref[c] != kEmptySlot) && !(tentry > bound);
+        key[c] = hit ? tentry : FLT_MAX;
+        kref[c] = hit ? ref[c] : kEmptySlot;
+    }
+#define RTX_CSWAP(a, b) { bool s = key[b] < key[a]; float tk = s ? key[b] : key[a]; float uk = s ? key[a] : key[b]; \
+                          uint32_t tr = s ? kref[b] : kref[a]; uint32_t ur = s ? kref[a] : kref[b]; key[a] = tk; key[b] = uk; kref[a] = tr; kref[b] = ur; }
+    RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
+#undef RTX_CSWAP
+    if (kref[3] != kEmptySlot) stk.push(kref[3], key[3]);
+    if (kref[2] != kEmptySlot) stk.push(kref[2], key[2]);
+    if (kref[1] != kEmptySlot) stk.push(kref[1], key[1]);
+    if (kref[0] != kEmptySlot) return kref[0];
+    return pop_next(stk, bound);
+}
+
+template <bool ANY, bool COUNT, int BLOCK, int LDS_N>
+__device__ __forceinline__ bool traverse_batched(const DeviceScene& sc, LaneStack<BLOCK, LDS_N>& stk,
+                                                 float ox, float oy, float oz, float dx, float dy, float dz,
+                                                 float maxT, HitRec& best, TravCount* cnt)
+{
+    best.t = FLT_MAX; best.u = 0; best.v = 0; best.pos = 0xFFFFFFFFu;
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    if (!slab_reference(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2],
+                        ox, oy, oz, ix, iy, iz))
+        return false;
+    const bool finite = (fabsf(ix) <= FLT_MAX) && (fabsf(iy) <= FLT_MAX) && (fabsf(iz) <= FLT_MAX);
+    if (!finite) { traverse_exact<ANY, BLOCK, LDS_N>(sc, stk, ox, oy, oz, dx, dy, dz, ix, iy, iz, maxT, best); return true; }
+    stk.sp = 0;
+    uint32_t cur = 0;
+    float bound = ANY ? (maxT + (fabsf(maxT) * kCullRel + kCullAbs)) : FLT_MAX;
+    for (;;) {
+        while (!(cur & kLeafBit) && cur != kDone) cur = step_inner<COUNT>(sc, stk, cur, ox, oy, oz, ix, iy, iz, bound, cnt);
+        if (cur == kDone) break;
+        const uint32_t first = cur & 0x07FFFFFFu, n = ((cur >> 27) & 15u) + 1u;
+        for (uint32_t k = 0; k < n; k++) {
+            TriIsect T = sc.tris[first + k];
+            if (COUNT) cnt->tris++;
+            float t, u, v;
+            if (tri_test(T, ox, oy, oz, dx, dy, dz, t, u, v)) {
+                if (ANY) { if (t <= maxT) { best.pos = first + k; best.t = t; return true; } }
+                else consider(best, t, u, v, first + k);
+            }
+        }
+        if (!ANY) bound = best.t + (fabsf(best.t) * kCullRel + kCullAbs);
+        cur = pop_next(stk, bound);
+    }
+    return true;
+}
+
 } // namespace rtx

@@ -1,0 +1,124 @@
+// traverse_dyn.h — BVH traversal with dynamic work fetch, the schedule every ray-query kernel
+// of the core runs on.
+//
+// One ray per lane, but a lane whose ray has finished does not idle until the slowest ray of
+// its wave is done: as soon as REFILL lanes of the wave are idle they take the next REFILL
+// items from a global counter (wave64 ballot + one atomic per wave). Items are handed out in
+// queue order, so the lanes that start together hold neighbouring rays, walk the same top
+// nodes and hit the same cache lines. Inside the loop the wave alternates two phases:
+// every lane descends inner nodes until it holds a leaf, then the wave tests leaf
+// triangles, TRI_UNROLL at a time so that their loads are in flight together.
+//
+// What is traversed and what is returned is identical to traverse() in traverse.h (same
+// candidates, same arithmetic, same tie-break); only the assignment of rays to lanes and
+// the order of independent steps differ.
+//
+// A Policy supplies the items and consumes the results:
+//   bool  fetch(uint32_t k, float o[3], float d[3], float& maxT)   load item k (k < n)
+//   void  retire(uint32_t k, const HitRec& best, bool reached)     reached == false: the ray missed the root box
+#pragma once
+
+#include "traverse.h"
+
+namespace rtx {
+
+template <class Policy, bool ANY, bool COUNT, int REFILL, int BLOCK, int LDS_N, int TRI_UNROLL>
+__device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BLOCK, LDS_N>& stk, uint32_t n, uint32_t* work_counter,
+                                             Policy& pol, unsigned long long* counters)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    TravCount cnt{0, 0};
+    uint32_t wave_iters[3] = {0, 0, 0};   // COUNT only: inner-loop, triangle-loop and outer-loop trips of this lane
+    uint32_t cur = kDone, item = kNone;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, bound = FLT_MAX, maxT = 0;
+    HitRec best; best.t = FLT_MAX; best.u = best.v = 0; best.pos = kNone;
+    bool exhausted = false;
+    for (;;) {
+        // retire finished rays
+        if (cur == kDone && item != kNone) { pol.retire(item, best, true); item = kNone; }
+        unsigned long long m = __ballot(cur == kDone);
+        uint32_t n_idle = (uint32_t)__popcll(m);
+        while (!exhausted && n_idle >= (uint32_t)REFILL) {
+            const bool idle = cur == kDone;
+            const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(work_counter, n_idle);
+            base = __shfl(base, (int)leader, 64);
+            if (idle) {
+                const uint32_t k = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (k < n) {
+                    float o[3], d[3];
+                    pol.fetch(k, o, d, maxT);
+                    ox = o[0]; oy = o[1]; oz = o[2]; dx = d[0]; dy = d[1]; dz = d[2];
+                    ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;                                    // Ray::init, Geometry.h:25
+                    best.t = FLT_MAX; best.u = best.v = 0; best.pos = kNone; stk.sp = 0;
+                    bound = ANY ? (maxT + (fabsf(maxT) * kCullRel + kCullAbs)) : FLT_MAX;
+                    // root box first (Geometry.h:509 / :571)
+                    if (slab_reference(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ox, oy, oz, ix, iy, iz)) {
+                        const bool finite = (fabsf(ix) <= FLT_MAX) && (fabsf(iy) <= FLT_MAX) && (fabsf(iz) <= FLT_MAX);
+                        if (finite) { cur = 0; item = k; }
+                        else { traverse_exact<ANY, BLOCK, LDS_N>(sc, stk, ox, oy, oz, dx, dy, dz, ix, iy, iz, maxT, best); pol.retire(k, best, true); }
+                    } else pol.retire(k, best, false);
+                }
+            }
+            if (base + n_idle >= n) exhausted = true;
+            m = __ballot(cur == kDone);
+            n_idle = (uint32_t)__popcll(m);
+        }
+        if (exhausted && __all(cur == kDone)) break;
+        if (COUNT) wave_iters[2]++;
+        // every lane descends until it holds a leaf
+        while (!(cur & kLeafBit) && cur != kDone) { if (COUNT) wave_iters[0]++; cur = step_inner<COUNT>(sc, stk, cur, ox, oy, oz, ix, iy, iz, bound, &cnt); }
+        if (cur != kDone) {
+            const uint32_t first = cur & 0x07FFFFFFu, nt = ((cur >> 27) & 15u) + 1u;
+            bool occluded = false;
+            for (uint32_t k = 0; k < nt; k += TRI_UNROLL) {
+                TriIsect T[TRI_UNROLL];
+#pragma unroll
+                for (int j = 0; j < TRI_UNROLL; j++) T[j] = sc.tris[first + min(k + (uint32_t)j, nt - 1u)];
+                if (COUNT) wave_iters[1]++;
+#pragma unroll
+                for (int j = 0; j < TRI_UNROLL; j++) {
+                    if (k + (uint32_t)j < nt) {
+                        if (COUNT) cnt.tris++;
+                        float t, u, v;
+                        if (tri_test(T[j], ox, oy, oz, dx, dy, dz, t, u, v)) {
+                            if (ANY) { if (t <= maxT && !occluded) { occluded = true; best.pos = first + k + (uint32_t)j; best.t = t; } }
+                            else consider(best, t, u, v, first + k + (uint32_t)j);
+                        }
+                    }
+                }
+                if (ANY && occluded) break;
+            }
+            if (ANY && occluded) cur = kDone;
+            else {
+                if (!ANY) bound = best.t + (fabsf(best.t) * kCullRel + kCullAbs);
+                cur = pop_next(stk, bound);
+            }
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&counters[0], (unsigned long long)cnt.nodes); atomicAdd(&counters[1], (unsigned long long)cnt.tris);
+        // wave-level trip counts: the maximum over the lanes of a wave is what the wave executed
+        for (int q = 0; q < 3; q++) {
+            uint32_t v = wave_iters[q];
+            for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+            if (lane == 0) atomicAdd(&counters[2 + q], (unsigned long long)v);
+        }
+    }
+}
+
+// Scene::visible's segment -> ray set-up, RTBase/Scene.h:170-178
+__device__ __forceinline__ void segment_to_ray(const float* s, float o[3], float d[3], float& maxT)
+{
+    float dx = s[3] - s[0], dy = s[4] - s[1], dz = s[5] - s[2];
+    float len2 = (dx * dx) + (dy * dy) + (dz * dz);
+    maxT = sqrtf(len2) - (2.0f * 0.001f);
+    float l = 1.0f / sqrtf(len2);
+    dx = dx * l; dy = dy * l; dz = dz * l;
+    d[0] = dx; d[1] = dy; d[2] = dz;
+    o[0] = s[0] + (dx * 0.001f); o[1] = s[1] + (dy * 0.001f); o[2] = s[2] + (dz * 0.001f);
+}
+
+} // namespace rtx

@@ -21,8 +21,13 @@ namespace rtx {
 
 constexpr uint32_t kFlagCanHitLight = 1u;   // emission counts at the next hit (Renderer.h:487,516)
 constexpr uint32_t kFlagStarted = 2u;       // slot carries a sample this pass
-constexpr int kCounterWords = 256;
+// counter words, zeroed once per pass: [0,96) live-queue lengths per depth, [96,192) shadow /
+// connection queue lengths per depth, [256,352) and [352,448) the work counters of the
+// closest-hit and shadow-ray launches of each depth (dynamic ray fetch)
+constexpr int kCounterWords = 512;
 constexpr int kShadowCounterBase = 96;
+constexpr int kClosestWorkBase = 256;
+constexpr int kShadowWorkBase = 352;
 
 struct WfPtrs {
     rtx_ray* ray; rtx_hit* hit;
@@ -248,19 +253,24 @@ __global__ __launch_bounds__(kBlock) void k_pt_shade(WfPtrs w, DeviceScene sc, P
 
 // Shadow rays of one depth: a visible segment adds its value to the path's radiance
 // (Renderer.h:448-452, 463-469).
-__global__ __launch_bounds__(kBlock) void k_shadow_accumulate(WfPtrs w, DeviceScene sc, uint32_t counter_index, uint2* spill, uint32_t spill_stride)
-{
-    __shared__ uint2 lds[kBlock * kLdsStack];
-    LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
-    const uint32_t n = w.cnt[counter_index];
-    for (uint32_t i = global_thread(); i < n; i += gridDim.x * kBlock) {
-        const float* s = w.sseg + 6 * (size_t)i;
-        if (segment_visible(sc, stk, s[0], s[1], s[2], s[3], s[4], s[5])) {
-            const uint32_t slot = w.spath[i];
-            C3 L = ldc(w.L + 3 * slot) + ldc(w.sval + 3 * (size_t)i);
+struct ShadowAccumulatePolicy {
+    const WfPtrs& w;
+    __device__ __forceinline__ void fetch(uint32_t k, float o[3], float d[3], float& maxT) const { segment_to_ray(w.sseg + 6 * (size_t)k, o, d, maxT); }
+    __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool reached) const
+    {
+        if (reached && best.pos == 0xFFFFFFFFu) {
+            const uint32_t slot = w.spath[k];
+            C3 L = ldc(w.L + 3 * slot) + ldc(w.sval + 3 * (size_t)k);
             st3(w.L + 3 * slot, L);
         }
     }
+};
+__global__ __launch_bounds__(kBlock) void k_shadow_accumulate(WfPtrs w, DeviceScene sc, uint32_t counter_index, uint32_t work_index, uint2* spill, uint32_t spill_stride)
+{
+    __shared__ uint2 lds[kBlock * kLdsStack];
+    LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
+    ShadowAccumulatePolicy pol{w};
+    traverse_dyn<ShadowAccumulatePolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, nullptr);
 }
 
 // film->splat(px, py, col) for every sample of the pass, Renderer.h:745
@@ -425,16 +435,21 @@ __global__ __launch_bounds__(kBlock) void k_lt_shade(WfPtrs w, DeviceScene sc, C
 }
 
 // Camera connections of one stage: visible ones splat onto the film (Renderer.h:325-331)
-__global__ __launch_bounds__(kBlock) void k_lt_splat(WfPtrs w, DeviceScene sc, uint32_t counter_index, int filter, uint2* spill, uint32_t spill_stride)
+struct SplatPolicy {
+    const WfPtrs& w; int filter;
+    __device__ __forceinline__ void fetch(uint32_t k, float o[3], float d[3], float& maxT) const { segment_to_ray(w.sseg + 6 * (size_t)k, o, d, maxT); }
+    __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool reached) const
+    {
+        if (reached && best.pos == 0xFFFFFFFFu)
+            film_splat(w.film, (int)w.W, (int)w.H, filter, w.sxy[2 * (size_t)k], w.sxy[2 * (size_t)k + 1], ldc(w.sval + 3 * (size_t)k));
+    }
+};
+__global__ __launch_bounds__(kBlock) void k_lt_splat(WfPtrs w, DeviceScene sc, uint32_t counter_index, uint32_t work_index, int filter, uint2* spill, uint32_t spill_stride)
 {
     __shared__ uint2 lds[kBlock * kLdsStack];
     LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
-    const uint32_t n = w.cnt[counter_index];
-    for (uint32_t i = global_thread(); i < n; i += gridDim.x * kBlock) {
-        const float* s = w.sseg + 6 * (size_t)i;
-        if (segment_visible(sc, stk, s[0], s[1], s[2], s[3], s[4], s[5]))
-            film_splat(w.film, (int)w.W, (int)w.H, filter, w.sxy[2 * (size_t)i], w.sxy[2 * (size_t)i + 1], ldc(w.sval + 3 * (size_t)i));
-    }
+    SplatPolicy pol{w, filter};
+    traverse_dyn<SplatPolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, nullptr);
 }
 
 // ---- instant radiosity: RTBase/Renderer.h:124-302 -------------------------------------------
@@ -621,7 +636,8 @@ inline int wavefront_render_pass(rtx_ctx* c)
     if (hipMemsetAsync(w.cnt, 0, kCounterWords * 4, s) != hipSuccess) return RTX_ERR_HIP;
 
     auto closest = [&](const uint32_t* queue, uint32_t counter) {
-        hipLaunchKernelGGL(k_closest_q, gridQ, blk, 0, s, c->dscene, (const rtx_ray*)w.ray, queue, (const uint32_t*)(w.cnt + counter), w.hit, spill, sstride);
+        hipLaunchKernelGGL(k_closest<false>, gridQ, blk, 0, s, c->dscene, (const rtx_ray*)w.ray, queue, 0u, (const uint32_t*)(w.cnt + counter), w.hit, spill, sstride,
+                           w.cnt + kClosestWorkBase + counter, (unsigned long long*)nullptr);
     };
     const bool algo = st.draw_mode == RTX_DM_ALGORITHM;
 
@@ -630,7 +646,7 @@ inline int wavefront_render_pass(rtx_ctx* c)
         hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
         closest(w.qa, 0);
         hipLaunchKernelGGL(k_dm_shade, gridQ, blk, 0, s, w, c->dscene, pp);
-        hipLaunchKernelGGL(k_shadow_accumulate, gridQ, blk, 0, s, w, c->dscene, (uint32_t)kShadowCounterBase, spill, sstride);
+        hipLaunchKernelGGL(k_shadow_accumulate, gridQ, blk, 0, s, w, c->dscene, (uint32_t)kShadowCounterBase, (uint32_t)kShadowWorkBase, spill, sstride);
         hipLaunchKernelGGL(k_film_accumulate, gridP, blk, 0, s, w, (int)st.filter);
         c->stats.samples += (uint64_t)w.W * w.H;
     } else if (st.algorithm == RTX_AL_PATH_TRACE) {
@@ -640,20 +656,20 @@ inline int wavefront_render_pass(rtx_ctx* c)
             pp.depth = d;
             closest(qin, d);
             hipLaunchKernelGGL(k_pt_shade, gridQ, blk, 0, s, w, c->dscene, pp, (const uint32_t*)qin, qout);
-            hipLaunchKernelGGL(k_shadow_accumulate, gridQ, blk, 0, s, w, c->dscene, (uint32_t)(kShadowCounterBase + d), spill, sstride);
+            hipLaunchKernelGGL(k_shadow_accumulate, gridQ, blk, 0, s, w, c->dscene, (uint32_t)(kShadowCounterBase + d), (uint32_t)(kShadowWorkBase + d), spill, sstride);
             std::swap(qin, qout);
         }
         hipLaunchKernelGGL(k_film_accumulate, gridP, blk, 0, s, w, (int)st.filter);
         c->stats.samples += (uint64_t)w.W * w.H;
     } else if (st.algorithm == RTX_AL_LIGHT_TRACE) {
         hipLaunchKernelGGL(k_lt_emit, gridP, blk, 0, s, w, c->dscene, c->dcam, pp);
-        hipLaunchKernelGGL(k_lt_splat, gridQ, blk, 0, s, w, c->dscene, (uint32_t)(kShadowCounterBase + 95), (int)st.filter, spill, sstride);
+        hipLaunchKernelGGL(k_lt_splat, gridQ, blk, 0, s, w, c->dscene, (uint32_t)(kShadowCounterBase + 95), (uint32_t)(kShadowWorkBase + 95), (int)st.filter, spill, sstride);
         uint32_t* qin = w.qa; uint32_t* qout = w.qb;
         for (uint32_t d = 0; d < st.max_bounces; d++) {
             pp.depth = d;
             closest(qin, d);
             hipLaunchKernelGGL(k_lt_shade, gridQ, blk, 0, s, w, c->dscene, c->dcam, pp, (const uint32_t*)qin, qout);
-            hipLaunchKernelGGL(k_lt_splat, gridQ, blk, 0, s, w, c->dscene, (uint32_t)(kShadowCounterBase + d), (int)st.filter, spill, sstride);
+            hipLaunchKernelGGL(k_lt_splat, gridQ, blk, 0, s, w, c->dscene, (uint32_t)(kShadowCounterBase + d), (uint32_t)(kShadowWorkBase + d), (int)st.filter, spill, sstride);
             std::swap(qin, qout);
         }
         c->stats.samples += (uint64_t)w.W * w.H;
