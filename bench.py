@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--no-pathtrace", action="store_true")
     ap.add_argument("--pt-spp", type=int, default=16, help="passes of the path-trace side measurement")
     ap.add_argument("--variants", default="", help="A/B: comma list of RTX_VARIANT values, interleaved rounds in one process")
+    ap.add_argument("--ab-scene", default="soup", choices=["soup", "mixed"])
+    ap.add_argument("--ab-rays", default="primary", choices=["primary", "bounce"], help="bounce: random directions from the primary hit points")
     args = ap.parse_args()
 
     import torch
@@ -62,9 +64,13 @@ def main():
     # enqueue on torch's current stream so torch events / synchronize see the kernels
     core.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    scene = scenes.soup(args.triangles, seed=12345)
+    if args.variants and args.ab_scene == "mixed":
+        scene = scenes.mixed_scene(128)
+        cam = pkg.look_at(lib, width=args.width, height=args.height, **scenes.mixed_camera())
+    else:
+        scene = scenes.soup(args.triangles, seed=12345)
+        cam = pkg.look_at(lib, (0, 0, 3.5), (0, 0, 0), (0, 1, 0), 45.0, args.width, args.height)
     core.upload_scene(scene)
-    cam = pkg.look_at(lib, (0, 0, 3.5), (0, 0, 0), (0, 1, 0), 45.0, args.width, args.height)
     core.set_camera(cam)
     n = args.width * args.height
     rays = torch.empty(n * RAY_BYTES, dtype=torch.uint8, device=dev)
@@ -73,6 +79,20 @@ def main():
     core.generate_primary_rays_device(rays.data_ptr(), pixel.data_ptr(), n)
     torch.cuda.synchronize()
 
+    if args.variants and args.ab_rays == "bounce":
+        core.trace_closest_device(rays.data_ptr(), n, hits.data_ptr())
+        torch.cuda.synchronize()
+        r = rays.view(torch.float32).view(n, 6)
+        t = hits.view(torch.float32).view(n, 5)[:, 1]
+        hit = hits.view(torch.int32).view(n, 5)[:, 0] != -1
+        g = torch.Generator(device=dev).manual_seed(7)
+        d = torch.randn(n, 3, generator=g, device=dev)
+        d = d / d.norm(dim=1, keepdim=True)
+        o = r[:, :3] + r[:, 3:] * t[:, None] + 1e-3 * d
+        rays = torch.cat([o, d], 1)[hit].contiguous().view(torch.uint8).view(-1)
+        n = int(hit.sum().item())
+        hits = torch.empty(n * HIT_BYTES, dtype=torch.uint8, device=dev)
+        print(json.dumps({"bounce_rays": n}))
     if args.variants:
         ab_variants(pkg, lib, scene, cam, args, rays, hits, n, torch, local_rank)
         return

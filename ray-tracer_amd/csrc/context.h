@@ -31,7 +31,8 @@ struct WavefrontBuffers;   // path-tracing state (wavefront.h)
 
 struct rtx_ctx {
     int device = 0;
-    int variant = 0;               // traversal schedule under test (RTX_VARIANT), 0 = default
+    int variant = 1;               // traversal schedule (RTX_VARIANT): 1 = default, 0 = static baseline, >= 2 = schedules under test
+    int resident_blocks = rtx::kMaxGridBlocks;   // traversal workgroups the device holds at once
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 

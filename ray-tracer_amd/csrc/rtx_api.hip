@@ -35,6 +35,8 @@ int upload(DevBuf& b, const std::vector<T>& v, hipStream_t s)
 }
 
 int grid_for(size_t n) { return (int)std::min<size_t>((n + kBlock - 1) / kBlock, kMaxGridBlocks); }
+// kernels that fetch their work dynamically only need the workgroups that are resident at once
+int dyn_grid_for(const rtx_ctx* c, size_t n) { return (int)std::min<size_t>((n + kBlock - 1) / kBlock, (size_t)c->resident_blocks); }
 
 int ensure_spill(rtx_ctx* c)
 {
@@ -63,9 +65,16 @@ int rtx_create(rtx_ctx** out, int device)
     if (const char* v = getenv("RTX_VARIANT")) c->variant = atoi(v);
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    {
+        // workgroups of the traversal kernels that fit on the device at once (LDS-bound)
+        int per_cu = 0; hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_closest<false>, kBlock, 0));
+        c->resident_blocks = std::max(1, std::min(kMaxGridBlocks, per_cu * prop.multiProcessorCount));
+    }
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
-    HIP_TRY(c->b_counters.ensure(256));
+    HIP_TRY(c->b_counters.ensure(4 * (1 + 2) * kWorkSlotWords));   // instrumentation counters, then the work-counter slots of the closest-hit and visibility launches
     // RayTracer's defaults, RTBase/Settings.h:40-61
     rtx_settings& s = c->settings;
     s.algorithm = RTX_AL_PATH_TRACE; s.draw_mode = RTX_DM_ALGORITHM; s.filter = RTX_FT_BOX;
@@ -275,15 +284,23 @@ int rtx_trace_closest_device(rtx_ctx* c, const rtx_ray* rays, size_t n, rtx_hit*
     if (!c->have_scene) return fail(RTX_ERR_STATE, "no scene uploaded");
     if (n == 0) return RTX_OK;
     if (!rays || !hits) return fail(RTX_ERR_INVALID, "null buffer");
-    if (n > 0xFFFFFFFFull) return fail(RTX_ERR_INVALID, "too many rays in one call");
+    if (n > 0xF0000000ull) return fail(RTX_ERR_INVALID, "too many rays in one call");
     if (c->variant == 0) {
         // A/B baseline: static assignment of rays to lanes (RTX_VARIANT=0)
         hipLaunchKernelGGL(k_closest_static, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, c->dscene, rays, (uint32_t)n, hits,
                            c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock));
+    } else if (c->variant >= 2) {
+        uint32_t* wc = c->b_counters.as<uint32_t>() + kWorkSlotWords;
+        HIP_TRY(hipMemsetAsync(wc, 0, kWorkSlotWords * 4, c->stream));
+        const uint32_t gb = (uint32_t)dyn_grid_for(c, n);
+#define RTX_AB(V, R, U, S, L) if (c->variant == V) hipLaunchKernelGGL((k_closest_ab<R, U, S, L>), dim3(gb), dim3(kBlock), 0, c->stream, c->dscene, rays, \
+                           (uint32_t)n, hits, c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), wc);
+        RTX_AB(2, 32, 4, 32, 12) RTX_AB(3, 16, 4, 32, 12) RTX_AB(4, 16, 2, 24, 12) RTX_AB(5, 16, 4, 0, 12)
+#undef RTX_AB
     } else {
-        uint32_t* wc = c->b_counters.as<uint32_t>() + 32;
-        HIP_TRY(hipMemsetAsync(wc, 0, 4, c->stream));
-        hipLaunchKernelGGL(k_closest<false>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, c->dscene, rays, (const uint32_t*)nullptr,
+        uint32_t* wc = c->b_counters.as<uint32_t>() + kWorkSlotWords;
+        HIP_TRY(hipMemsetAsync(wc, 0, kWorkSlotWords * 4, c->stream));
+        hipLaunchKernelGGL(k_closest<false>, dim3(dyn_grid_for(c, n)), dim3(kBlock), 0, c->stream, c->dscene, rays, (const uint32_t*)nullptr,
                            (uint32_t)n, (const uint32_t*)nullptr, hits, c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), wc,
                            (unsigned long long*)nullptr);
     }
@@ -313,10 +330,10 @@ int rtx_trace_visible_device(rtx_ctx* c, const float* p1p2, size_t n, uint8_t* v
     if (!c->have_scene) return fail(RTX_ERR_STATE, "no scene uploaded");
     if (n == 0) return RTX_OK;
     if (!p1p2 || !vis) return fail(RTX_ERR_INVALID, "null buffer");
-    if (n > 0xFFFFFFFFull) return fail(RTX_ERR_INVALID, "too many segments in one call");
-    uint32_t* wc = c->b_counters.as<uint32_t>() + 33;
-    HIP_TRY(hipMemsetAsync(wc, 0, 4, c->stream));
-    hipLaunchKernelGGL(k_visible, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, c->dscene, p1p2, (uint32_t)n, vis,
+    if (n > 0xF0000000ull) return fail(RTX_ERR_INVALID, "too many segments in one call");
+    uint32_t* wc = c->b_counters.as<uint32_t>() + 2 * kWorkSlotWords;
+    HIP_TRY(hipMemsetAsync(wc, 0, kWorkSlotWords * 4, c->stream));
+    hipLaunchKernelGGL(k_visible, dim3(dyn_grid_for(c, n)), dim3(kBlock), 0, c->stream, c->dscene, p1p2, (uint32_t)n, vis,
                        c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), wc);
     HIP_TRY(hipGetLastError());
     c->stats.shadow_rays += n;
@@ -354,12 +371,12 @@ int rtx_count_closest_work(rtx_ctx* c, const rtx_ray* rays, size_t n, uint64_t* 
 {
     CTX_TRY(c);
     if (!c->have_scene) return fail(RTX_ERR_STATE, "no scene uploaded");
-    if (!rays || !nodes || !tris || n == 0 || n > 0xFFFFFFFFull) return fail(RTX_ERR_INVALID, "bad argument");
+    if (!rays || !nodes || !tris || n == 0 || n > 0xF0000000ull) return fail(RTX_ERR_INVALID, "bad argument");
     HIP_TRY(c->b_io_b.ensure(n * sizeof(rtx_hit)));
-    HIP_TRY(hipMemsetAsync(c->b_counters.p, 0, 256, c->stream));
-    hipLaunchKernelGGL(k_closest<true>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, c->dscene, rays, (const uint32_t*)nullptr,
+    HIP_TRY(hipMemsetAsync(c->b_counters.p, 0, 4 * 2 * kWorkSlotWords, c->stream));
+    hipLaunchKernelGGL(k_closest<true>, dim3(dyn_grid_for(c, n)), dim3(kBlock), 0, c->stream, c->dscene, rays, (const uint32_t*)nullptr,
                        (uint32_t)n, (const uint32_t*)nullptr, c->b_io_b.as<rtx_hit>(), c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock),
-                       c->b_counters.as<uint32_t>() + 32, c->b_counters.as<unsigned long long>());
+                       c->b_counters.as<uint32_t>() + kWorkSlotWords, c->b_counters.as<unsigned long long>());
     HIP_TRY(hipGetLastError());
     unsigned long long h[5];
     HIP_TRY(hipMemcpyAsync(h, c->b_counters.p, 40, hipMemcpyDeviceToHost, c->stream));

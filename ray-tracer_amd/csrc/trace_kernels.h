@@ -8,8 +8,9 @@
 namespace rtx {
 
 constexpr float kEpsilon = 0.001f;    // EPSILON, RTBase/Geometry.h:54
-constexpr int kRefill = 32;           // idle lanes that trigger a fetch of new rays
+constexpr int kRefill = 16;           // idle lanes that trigger a fetch of new rays
 constexpr int kTriUnroll = 4;         // leaf triangles whose loads are issued together
+constexpr int kLeafLanes = 24;        // the wave stops descending and tests triangles once this many lanes hold a leaf
 
 __device__ __forceinline__ uint32_t global_thread() { return blockIdx.x * kBlock + threadIdx.x; }
 
@@ -78,7 +79,18 @@ __global__ __launch_bounds__(kBlock) void k_closest(DeviceScene sc, const rtx_ra
     __shared__ uint2 lds[kBlock * kLdsStack];
     LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
     ClosestPolicy pol{sc, rays, queue, hits};
-    traverse_dyn<ClosestPolicy, false, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll>(sc, stk, n_dev ? *n_dev : n_host, work_counter, pol, counters);
+    traverse_dyn<ClosestPolicy, false, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes>(sc, stk, n_dev ? *n_dev : n_host, work_counter, pol, counters);
+}
+
+// Schedules under test (A/B harness only)
+template <int REFILL, int UNROLL, int SCHED, int LDS_N>
+__global__ __launch_bounds__(kBlock) void k_closest_ab(DeviceScene sc, const rtx_ray* __restrict__ rays, uint32_t n, rtx_hit* __restrict__ hits,
+                                                       uint2* spill, uint32_t spill_stride, uint32_t* work_counter)
+{
+    __shared__ uint2 lds[kBlock * LDS_N];
+    LaneStack<kBlock, LDS_N> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
+    ClosestPolicy pol{sc, rays, nullptr, hits};
+    traverse_dyn<ClosestPolicy, false, false, REFILL, kBlock, LDS_N, UNROLL, SCHED>(sc, stk, n, work_counter, pol, nullptr);
 }
 
 // ---- visibility: Scene::visible, RTBase/Scene.h:170-178 -> traverseVisible, Geometry.h:568-610 ----
@@ -95,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void k_visible(DeviceScene sc, const float*
     __shared__ uint2 lds[kBlock * kLdsStack];
     LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
     VisiblePolicy pol{p1p2, visible};
-    traverse_dyn<VisiblePolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll>(sc, stk, n, work_counter, pol, nullptr);
+    traverse_dyn<VisiblePolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes>(sc, stk, n, work_counter, pol, nullptr);
 }
 
 // One segment, inside a kernel that loops over segments per lane (the VPL gather)

@@ -2,8 +2,8 @@
 // of the core runs on.
 //
 // One ray per lane, but a lane whose ray has finished does not idle until the slowest ray of
-// its wave is done: as soon as REFILL lanes of the wave are idle they take the next REFILL
-// items from a global counter (wave64 ballot + one atomic per wave). Items are handed out in
+// its wave is done: as soon as REFILL lanes of the wave are idle they take the next items of
+// the wave's reserved chunk (wave64 ballot; one atomic per chunk). Items are handed out in
 // queue order, so the lanes that start together hold neighbouring rays, walk the same top
 // nodes and hit the same cache lines. Inside the loop the wave alternates two phases:
 // every lane descends inner nodes until it holds a leaf, then the wave tests leaf
@@ -22,8 +22,25 @@
 
 namespace rtx {
 
-template <class Policy, bool ANY, bool COUNT, int REFILL, int BLOCK, int LDS_N, int TRI_UNROLL>
-__device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BLOCK, LDS_N>& stk, uint32_t n, uint32_t* work_counter,
+// Work counters of one traversal launch: kWorkSegments counters (one per lane of a wave,
+// so that a wave can read them all with one load), kWorkStride words apart, all zero at
+// launch.
+constexpr int kWorkSegments = 64;
+constexpr int kWorkStride = 32;
+constexpr int kWorkSlotWords = kWorkSegments * kWorkStride;
+
+// The chunk that counter `seg` hands out as its j-th. Four consecutive chunks (four
+// neighbouring 8x8 pixel tiles of a primary-ray queue) come from the same counter, whose
+// users are the waves of a few workgroups, and eight consecutive groups of four from the
+// eight counters of one XCD (workgroup b runs on XCD b % 8 and draws from counter b % 64),
+// so that neighbouring rays meet in the same L1 / L2.
+__device__ __forceinline__ uint32_t work_chunk(uint32_t j, uint32_t seg)
+{
+    return (((j >> 2) * (uint32_t)kWorkSegments + (seg & 7u) * 8u + (seg >> 3)) << 2) + (j & 3u);
+}
+
+template <class Policy, bool ANY, bool COUNT, int REFILL, int BLOCK, int LDS_N, int TRI_UNROLL, int SCHED>
+__device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BLOCK, LDS_N>& stk, uint32_t n, uint32_t* work,
                                              Policy& pol, unsigned long long* counters)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -33,6 +50,15 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
     uint32_t cur = kDone, item = kNone;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, bound = FLT_MAX, maxT = 0;
     HitRec best; best.t = FLT_MAX; best.u = best.v = 0; best.pos = kNone;
+    // Work distribution. Items are handed out in chunks of 64. Chunk g belongs to counter
+    // g % kWorkSegments, and counter s hands out its chunks in ascending order, so that the
+    // whole grid sweeps through the items on one front (neighbouring rays are in flight
+    // together and find each other's nodes in the caches) while the fetch atomics are spread
+    // over kWorkSegments addresses instead of queueing on one. A wave draws from the counter
+    // of its workgroup; when that one has run dry it looks at all counters at once (one
+    // coherent load per lane) and moves to one that still has chunks. Wave-uniform state.
+    const uint32_t n_chunks = (n + 63u) / 64u;
+    uint32_t seg = blockIdx.x % (uint32_t)kWorkSegments, loc_next = 0, loc_end = 0;
     bool exhausted = false;
     for (;;) {
         // retire finished rays
@@ -40,37 +66,62 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
         unsigned long long m = __ballot(cur == kDone);
         uint32_t n_idle = (uint32_t)__popcll(m);
         while (!exhausted && n_idle >= (uint32_t)REFILL) {
-            const bool idle = cur == kDone;
-            const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(work_counter, n_idle);
-            base = __shfl(base, (int)leader, 64);
-            if (idle) {
-                const uint32_t k = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (k < n) {
-                    float o[3], d[3];
-                    pol.fetch(k, o, d, maxT);
-                    ox = o[0]; oy = o[1]; oz = o[2]; dx = d[0]; dy = d[1]; dz = d[2];
-                    ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;                                    // Ray::init, Geometry.h:25
-                    best.t = FLT_MAX; best.u = best.v = 0; best.pos = kNone; stk.sp = 0;
-                    bound = ANY ? (maxT + (fabsf(maxT) * kCullRel + kCullAbs)) : FLT_MAX;
-                    // root box first (Geometry.h:509 / :571)
-                    if (slab_reference(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ox, oy, oz, ix, iy, iz)) {
-                        const bool finite = (fabsf(ix) <= FLT_MAX) && (fabsf(iy) <= FLT_MAX) && (fabsf(iz) <= FLT_MAX);
-                        if (finite) { cur = 0; item = k; }
-                        else { traverse_exact<ANY, BLOCK, LDS_N>(sc, stk, ox, oy, oz, dx, dy, dz, ix, iy, iz, maxT, best); pol.retire(k, best, true); }
-                    } else pol.retire(k, best, false);
+            if (loc_next == loc_end) {
+                uint32_t j = 0;
+                if (lane == 0) j = atomicAdd(work + seg * (uint32_t)kWorkStride, 1u);
+                j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+                // chunk index j * kWorkSegments + seg; j is far below 2^26 because n < 2^32
+                const uint32_t g = work_chunk(j, seg);
+                if (j >= (1u << 26) || g >= n_chunks) {
+                    // this counter is dry: which ones are not?
+                    const uint32_t cj = __hip_atomic_load(work + lane * (uint32_t)kWorkStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long live = __ballot(cj < (1u << 26) && work_chunk(cj, lane) < n_chunks);
+                    if (live == 0ull) { exhausted = true; continue; }
+                    // nearest live counter after this one, cyclically
+                    const unsigned long long rot = seg ? ((live >> seg) | (live << (64u - seg))) : live;
+                    seg = (seg + (uint32_t)__ffsll((long long)rot) - 1u) & 63u;
+                    continue;
                 }
+                loc_next = g * 64u; loc_end = min(loc_next + 64u, n);
             }
-            if (base + n_idle >= n) exhausted = true;
+            const uint32_t take = min(n_idle, loc_end - loc_next);
+            const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (cur == kDone && rank < take) {
+                const uint32_t k = loc_next + rank;
+                float o[3], d[3];
+                pol.fetch(k, o, d, maxT);
+                ox = o[0]; oy = o[1]; oz = o[2]; dx = d[0]; dy = d[1]; dz = d[2];
+                ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;                                    // Ray::init, Geometry.h:25
+                best.t = FLT_MAX; best.u = best.v = 0; best.pos = kNone; stk.sp = 0;
+                bound = ANY ? (maxT + (fabsf(maxT) * kCullRel + kCullAbs)) : FLT_MAX;
+                // root box first (Geometry.h:509 / :571)
+                if (slab_reference(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ox, oy, oz, ix, iy, iz)) {
+                    const bool finite = (fabsf(ix) <= FLT_MAX) && (fabsf(iy) <= FLT_MAX) && (fabsf(iz) <= FLT_MAX);
+                    if (finite) { cur = 0; item = k; }
+                    else { traverse_exact<ANY, BLOCK, LDS_N>(sc, stk, ox, oy, oz, dx, dy, dz, ix, iy, iz, maxT, best); pol.retire(k, best, true); }
+                } else pol.retire(k, best, false);
+            }
+            loc_next += take;
             m = __ballot(cur == kDone);
             n_idle = (uint32_t)__popcll(m);
         }
         if (exhausted && __all(cur == kDone)) break;
         if (COUNT) wave_iters[2]++;
         // every lane descends until it holds a leaf
-        while (!(cur & kLeafBit) && cur != kDone) { if (COUNT) wave_iters[0]++; cur = step_inner<COUNT>(sc, stk, cur, ox, oy, oz, ix, iy, iz, bound, &cnt); }
-        if (cur != kDone) {
+        if (SCHED == 0) {
+            while (!(cur & kLeafBit) && cur != kDone) { if (COUNT) wave_iters[0]++; cur = step_inner<COUNT>(sc, stk, cur, ox, oy, oz, ix, iy, iz, bound, &cnt); }
+        } else if (SCHED == 1) {
+            if (!(cur & kLeafBit) && cur != kDone) { if (COUNT) wave_iters[0]++; cur = step_inner<COUNT>(sc, stk, cur, ox, oy, oz, ix, iy, iz, bound, &cnt); }
+        } else {
+            // descend until SCHED lanes hold a leaf (or nobody has an inner node left)
+            for (;;) {
+                const bool inner = !(cur & kLeafBit) && cur != kDone;
+                if (!__any(inner)) break;
+                if (inner) { if (COUNT) wave_iters[0]++; cur = step_inner<COUNT>(sc, stk, cur, ox, oy, oz, ix, iy, iz, bound, &cnt); }
+                if (__popcll(__ballot((cur & kLeafBit) != 0)) >= SCHED) break;
+            }
+        }
+        if (cur & kLeafBit) {
             const uint32_t first = cur & 0x07FFFFFFu, nt = ((cur >> 27) & 15u) + 1u;
             bool occluded = false;
             for (uint32_t k = 0; k < nt; k += TRI_UNROLL) {

@@ -24,10 +24,10 @@ constexpr uint32_t kFlagStarted = 2u;       // slot carries a sample this pass
 // counter words, zeroed once per pass: [0,96) live-queue lengths per depth, [96,192) shadow /
 // connection queue lengths per depth, [256,352) and [352,448) the work counters of the
 // closest-hit and shadow-ray launches of each depth (dynamic ray fetch)
-constexpr int kCounterWords = 512;
 constexpr int kShadowCounterBase = 96;
-constexpr int kClosestWorkBase = 256;
-constexpr int kShadowWorkBase = 352;
+constexpr int kClosestWorkBase = 256;                                       // 96 work-counter slots of the closest-hit launches
+constexpr int kShadowWorkBase = kClosestWorkBase + 96 * kWorkSlotWords;     // 96 slots of the shadow / splat launches
+constexpr int kCounterWords = kShadowWorkBase + 96 * kWorkSlotWords;
 
 struct WfPtrs {
     rtx_ray* ray; rtx_hit* hit;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_accumulate(WfPtrs w, DeviceSc
     __shared__ uint2 lds[kBlock * kLdsStack];
     LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
     ShadowAccumulatePolicy pol{w};
-    traverse_dyn<ShadowAccumulatePolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, nullptr);
+    traverse_dyn<ShadowAccumulatePolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, nullptr);
 }
 
 // film->splat(px, py, col) for every sample of the pass, Renderer.h:745
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(kBlock) void k_lt_splat(WfPtrs w, DeviceScene sc, u
     __shared__ uint2 lds[kBlock * kLdsStack];
     LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
     SplatPolicy pol{w, filter};
-    traverse_dyn<SplatPolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, nullptr);
+    traverse_dyn<SplatPolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, nullptr);
 }
 
 // ---- instant radiosity: RTBase/Renderer.h:124-302 -------------------------------------------
@@ -627,7 +627,8 @@ inline int wavefront_render_pass(rtx_ctx* c)
 {
     if (!c->wf) return RTX_ERR_STATE;
     WavefrontBuffers& b = *c->wf; WfPtrs& w = b.p; const rtx_settings& st = c->settings; hipStream_t s = c->stream;
-    const dim3 blk(kBlock), gridP((w.P + kBlock - 1) / kBlock), gridQ(std::min<uint32_t>((w.P + kBlock - 1) / kBlock, kMaxGridBlocks));
+    const dim3 blk(kBlock), gridP((w.P + kBlock - 1) / kBlock), gridQ(std::min<uint32_t>((w.P + kBlock - 1) / kBlock, kMaxGridBlocks)),
+               gridT(std::min<uint32_t>((w.P + kBlock - 1) / kBlock, (uint32_t)c->resident_blocks));   // traversal kernels fetch work dynamically
     uint2* spill = c->b_spill.as<uint2>(); const uint32_t sstride = kMaxGridBlocks * kBlock;
 
     c->spp++;                                            // Film::incrementSPP, RTBase/Imaging.h:403
@@ -636,8 +637,8 @@ inline int wavefront_render_pass(rtx_ctx* c)
     if (hipMemsetAsync(w.cnt, 0, kCounterWords * 4, s) != hipSuccess) return RTX_ERR_HIP;
 
     auto closest = [&](const uint32_t* queue, uint32_t counter) {
-        hipLaunchKernelGGL(k_closest<false>, gridQ, blk, 0, s, c->dscene, (const rtx_ray*)w.ray, queue, 0u, (const uint32_t*)(w.cnt + counter), w.hit, spill, sstride,
-                           w.cnt + kClosestWorkBase + counter, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL(k_closest<false>, gridT, blk, 0, s, c->dscene, (const rtx_ray*)w.ray, queue, 0u, (const uint32_t*)(w.cnt + counter), w.hit, spill, sstride,
+                           w.cnt + kClosestWorkBase + counter * kWorkSlotWords, (unsigned long long*)nullptr);
     };
     const bool algo = st.draw_mode == RTX_DM_ALGORITHM;
 
@@ -646,7 +647,7 @@ inline int wavefront_render_pass(rtx_ctx* c)
         hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
         closest(w.qa, 0);
         hipLaunchKernelGGL(k_dm_shade, gridQ, blk, 0, s, w, c->dscene, pp);
-        hipLaunchKernelGGL(k_shadow_accumulate, gridQ, blk, 0, s, w, c->dscene, (uint32_t)kShadowCounterBase, (uint32_t)kShadowWorkBase, spill, sstride);
+        hipLaunchKernelGGL(k_shadow_accumulate, gridT, blk, 0, s, w, c->dscene, (uint32_t)kShadowCounterBase, (uint32_t)kShadowWorkBase, spill, sstride);
         hipLaunchKernelGGL(k_film_accumulate, gridP, blk, 0, s, w, (int)st.filter);
         c->stats.samples += (uint64_t)w.W * w.H;
     } else if (st.algorithm == RTX_AL_PATH_TRACE) {
@@ -656,20 +657,20 @@ inline int wavefront_render_pass(rtx_ctx* c)
             pp.depth = d;
             closest(qin, d);
             hipLaunchKernelGGL(k_pt_shade, gridQ, blk, 0, s, w, c->dscene, pp, (const uint32_t*)qin, qout);
-            hipLaunchKernelGGL(k_shadow_accumulate, gridQ, blk, 0, s, w, c->dscene, (uint32_t)(kShadowCounterBase + d), (uint32_t)(kShadowWorkBase + d), spill, sstride);
+            hipLaunchKernelGGL(k_shadow_accumulate, gridT, blk, 0, s, w, c->dscene, (uint32_t)(kShadowCounterBase + d), (uint32_t)(kShadowWorkBase + d * kWorkSlotWords), spill, sstride);
             std::swap(qin, qout);
         }
         hipLaunchKernelGGL(k_film_accumulate, gridP, blk, 0, s, w, (int)st.filter);
         c->stats.samples += (uint64_t)w.W * w.H;
     } else if (st.algorithm == RTX_AL_LIGHT_TRACE) {
         hipLaunchKernelGGL(k_lt_emit, gridP, blk, 0, s, w, c->dscene, c->dcam, pp);
-        hipLaunchKernelGGL(k_lt_splat, gridQ, blk, 0, s, w, c->dscene, (uint32_t)(kShadowCounterBase + 95), (uint32_t)(kShadowWorkBase + 95), (int)st.filter, spill, sstride);
+        hipLaunchKernelGGL(k_lt_splat, gridT, blk, 0, s, w, c->dscene, (uint32_t)(kShadowCounterBase + 95), (uint32_t)(kShadowWorkBase + 95 * kWorkSlotWords), (int)st.filter, spill, sstride);
         uint32_t* qin = w.qa; uint32_t* qout = w.qb;
         for (uint32_t d = 0; d < st.max_bounces; d++) {
             pp.depth = d;
             closest(qin, d);
             hipLaunchKernelGGL(k_lt_shade, gridQ, blk, 0, s, w, c->dscene, c->dcam, pp, (const uint32_t*)qin, qout);
-            hipLaunchKernelGGL(k_lt_splat, gridQ, blk, 0, s, w, c->dscene, (uint32_t)(kShadowCounterBase + d), (uint32_t)(kShadowWorkBase + d), (int)st.filter, spill, sstride);
+            hipLaunchKernelGGL(k_lt_splat, gridT, blk, 0, s, w, c->dscene, (uint32_t)(kShadowCounterBase + d), (uint32_t)(kShadowWorkBase + d * kWorkSlotWords), (int)st.filter, spill, sstride);
             std::swap(qin, qout);
         }
         c->stats.samples += (uint64_t)w.W * w.H;
