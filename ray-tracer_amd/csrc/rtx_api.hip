@@ -71,6 +71,8 @@ int rtx_create(rtx_ctx** out, int device)
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_closest<false>, kBlock, 0));
         c->resident_blocks = std::max(1, std::min(kMaxGridBlocks, per_cu * prop.multiProcessorCount));
+        if (const char* g = getenv("RTX_GRID")) c->resident_blocks = std::max(1, std::min(kMaxGridBlocks, atoi(g)));   // tuning override
+        if (getenv("RTX_DEBUG_COUNTERS")) fprintf(stderr, "[rtx] %d CUs x %d resident traversal workgroups\n", prop.multiProcessorCount, per_cu);
     }
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
