@@ -44,11 +44,12 @@ struct WfPtrs {
     float* vpl;        // [V][10] x(3) n(3) Le(3) valid
     uint32_t* vpl_total;
     float* film; uint32_t* tile_samples;
+    uint32_t* tile_off;   // [n_tiles] queue offset of the tile's first camera sample this pass
     uint32_t P, W, H, tiles_x, n_tiles, vpl_slots;
 };
 
 struct WavefrontBuffers {
-    DevBuf ray, hit, T, L, xy, key, dim, mis, flags, qa, qb, cnt, sseg, sval, sxy, spath, vpl, vpl_total;
+    DevBuf ray, hit, T, L, xy, key, dim, mis, flags, qa, qb, cnt, sseg, sval, sxy, spath, vpl, vpl_total, tile_off;
     WfPtrs p{};
     uint32_t vpl_capacity = 0;
 };
@@ -59,17 +60,27 @@ struct PassParams {
 
 // ---- small device helpers -------------------------------------------------------------------
 
-// Append to a queue: one atomic per wave, lanes take consecutive places.
+// Append to a queue: one atomic per workgroup (returning atomics on one address complete at
+// roughly one per 11 ns, so the number of them per launch matters); the lanes that push
+// take consecutive places. Every thread of the workgroup must call this, from uniform
+// control flow.
 __device__ __forceinline__ uint32_t queue_slot(bool push, uint32_t* counter)
 {
+    __shared__ uint32_t s_count[kBlock / 64], s_base;
     const unsigned long long mask = __ballot(push);
-    if (!push) return 0xFFFFFFFFu;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, (int)leader, 64);
-    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) s_count[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int i = 0; i < kBlock / 64; i++) total += s_count[i];
+        s_base = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t at = s_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    for (uint32_t i = 0; i < wave; i++) at += s_count[i];
+    __syncthreads();                        // the next call may overwrite the counts
+    return push ? at : 0xFFFFFFFFu;
 }
 
 __device__ __forceinline__ void slot_pixel(uint32_t slot, uint32_t tiles_x, uint32_t& tile, uint32_t& x, uint32_t& y)
@@ -189,8 +200,53 @@ __global__ __launch_bounds__(kBlock) void k_raygen(WfPtrs w, CameraDev cam, Pass
         w.L[3 * slot] = 0.0f; w.L[3 * slot + 1] = 0.0f; w.L[3 * slot + 2] = 0.0f;
         w.flags[slot] = kFlagStarted | (pp.st.can_hit_light ? kFlagCanHitLight : 0u);
     }
-    uint32_t q = queue_slot(active, &w.cnt[0]);
-    if (active) w.qa[q] = slot;
+    // place in the queue: the tile's offset (k_tile_offsets) + rank inside the tile, no atomics
+    __shared__ uint32_t s_count[kBlock / 64];
+    const unsigned long long mask = __ballot(active);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) s_count[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (active) {
+        uint32_t q = w.tile_off[blockIdx.x] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        for (uint32_t i = 0; i < wave; i++) q += s_count[i];
+        w.qa[q] = slot;
+    }
+}
+
+// Queue offset of every tile's first camera sample (tiles are skipped by adaptive sampling
+// and by the tile split across GPUs) and the queue length; one workgroup.
+__global__ __launch_bounds__(1024) void k_tile_offsets(WfPtrs w, PassParams pp)
+{
+    __shared__ uint32_t s_part[1024];
+    const uint32_t per = (w.n_tiles + 1023u) / 1024u, t0 = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t tile = t0 + k;
+        if (tile < w.n_tiles && tile_active(w, pp, tile)) {
+            const uint32_t sx = (tile % w.tiles_x) * 16u, sy = (tile / w.tiles_x) * 16u;
+            sum += (min(sx + 16u, w.W) - sx) * (min(sy + 16u, w.H) - sy);
+        }
+    }
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024u; o <<= 1) {
+        const uint32_t v = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[threadIdx.x] - sum;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t tile = t0 + k;
+        if (tile < w.n_tiles) {
+            w.tile_off[tile] = run;
+            if (tile_active(w, pp, tile)) {
+                const uint32_t sx = (tile % w.tiles_x) * 16u, sy = (tile / w.tiles_x) * 16u;
+                run += (min(sx + 16u, w.W) - sx) * (min(sy + 16u, w.H) - sy);
+            }
+        }
+    }
+    if (threadIdx.x == 1023u) w.cnt[0] = s_part[1023];
 }
 
 // One depth of RayTracer::pathTrace, RTBase/Renderer.h:476-526, for every live path.
@@ -599,14 +655,14 @@ inline int wavefront_resize(rtx_ctx* c)
     RTX_ENS(b.ray, P * sizeof(rtx_ray)); RTX_ENS(b.hit, P * sizeof(rtx_hit)); RTX_ENS(b.T, P * 12); RTX_ENS(b.L, P * 12);
     RTX_ENS(b.xy, P * 8); RTX_ENS(b.key, P * 4); RTX_ENS(b.dim, P * 4); RTX_ENS(b.mis, P * 4); RTX_ENS(b.flags, P * 4);
     RTX_ENS(b.qa, P * 4); RTX_ENS(b.qb, P * 4); RTX_ENS(b.cnt, kCounterWords * 4);
-    RTX_ENS(b.sseg, P * 24); RTX_ENS(b.sval, P * 12); RTX_ENS(b.sxy, P * 8); RTX_ENS(b.spath, P * 4); RTX_ENS(b.vpl_total, 16);
+    RTX_ENS(b.sseg, P * 24); RTX_ENS(b.sval, P * 12); RTX_ENS(b.sxy, P * 8); RTX_ENS(b.spath, P * 4); RTX_ENS(b.vpl_total, 16); RTX_ENS(b.tile_off, P / 256 * 4);
 #undef RTX_ENS
     WfPtrs& p = b.p;
     p.ray = b.ray.as<rtx_ray>(); p.hit = b.hit.as<rtx_hit>(); p.T = b.T.as<float>(); p.L = b.L.as<float>(); p.xy = b.xy.as<float>();
     p.key = b.key.as<uint32_t>(); p.dim = b.dim.as<uint32_t>(); p.mis = b.mis.as<float>(); p.flags = b.flags.as<uint32_t>();
     p.qa = b.qa.as<uint32_t>(); p.qb = b.qb.as<uint32_t>(); p.cnt = b.cnt.as<uint32_t>();
     p.sseg = b.sseg.as<float>(); p.sval = b.sval.as<float>(); p.sxy = b.sxy.as<float>(); p.spath = b.spath.as<uint32_t>();
-    p.vpl_total = b.vpl_total.as<uint32_t>();
+    p.vpl_total = b.vpl_total.as<uint32_t>(); p.tile_off = b.tile_off.as<uint32_t>();
     p.film = c->b_film.as<float>(); p.tile_samples = c->b_tile_samples.as<uint32_t>();
     p.P = (uint32_t)P; p.W = (uint32_t)c->cam.width; p.H = (uint32_t)c->cam.height; p.tiles_x = c->tiles_x; p.n_tiles = c->tiles_x * c->tiles_y;
     // tileSamples.resize(totalTiles, 1), RTBase/Renderer.h:112
@@ -644,6 +700,7 @@ inline int wavefront_render_pass(rtx_ctx* c)
 
     if (!algo) {
         // RTBase/Renderer.h:699-720
+        hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, w, pp);
         hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
         closest(w.qa, 0);
         hipLaunchKernelGGL(k_dm_shade, gridQ, blk, 0, s, w, c->dscene, pp);
@@ -651,6 +708,7 @@ inline int wavefront_render_pass(rtx_ctx* c)
         hipLaunchKernelGGL(k_film_accumulate, gridP, blk, 0, s, w, (int)st.filter);
         c->stats.samples += (uint64_t)w.W * w.H;
     } else if (st.algorithm == RTX_AL_PATH_TRACE) {
+        hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, w, pp);
         hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
         uint32_t* qin = w.qa; uint32_t* qout = w.qb;
         for (uint32_t d = 0; d <= st.max_bounces; d++) {
@@ -696,6 +754,7 @@ inline int wavefront_render_pass(rtx_ctx* c)
         // per-pixel gather, RTBase/Renderer.h:730-745
         pp.depth = 0;
         if (hipMemsetAsync(w.cnt, 0, kCounterWords * 4, s) != hipSuccess) return RTX_ERR_HIP;
+        hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, w, pp);
         hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
         closest(w.qa, 0);
         hipLaunchKernelGGL(k_ir_gather, gridQ, blk, 0, s, w, c->dscene, pp, spill, sstride);
