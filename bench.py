@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--pt-spp", type=int, default=16, help="passes of the path-trace side measurement")
     ap.add_argument("--variants", default="", help="A/B: comma list of RTX_VARIANT values, interleaved rounds in one process")
     ap.add_argument("--ab-scene", default="soup", choices=["soup", "mixed"])
+    ap.add_argument("--ab-count", type=int, default=0, help="A/B: keep only this many rays (random subset)")
     ap.add_argument("--ab-rays", default="primary", choices=["primary", "bounce"], help="bounce: random directions from the primary hit points")
     args = ap.parse_args()
 
@@ -93,6 +94,12 @@ def main():
         n = int(hit.sum().item())
         hits = torch.empty(n * HIT_BYTES, dtype=torch.uint8, device=dev)
         print(json.dumps({"bounce_rays": n}))
+    if args.variants and args.ab_count and args.ab_count < n:
+        g = torch.Generator(device=dev).manual_seed(11)
+        keep = torch.randperm(n, generator=g, device=dev)[:args.ab_count].sort().values
+        rays = rays.view(n, RAY_BYTES)[keep].contiguous().view(-1)
+        n = args.ab_count
+        hits = torch.empty(n * HIT_BYTES, dtype=torch.uint8, device=dev)
     if args.variants:
         ab_variants(pkg, lib, scene, cam, args, rays, hits, n, torch, local_rank)
         return

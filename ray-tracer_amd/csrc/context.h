@@ -15,6 +15,7 @@ constexpr int kBlock = 256;        // threads per workgroup (4 waves)
 constexpr int kLdsStack = 12;      // traversal-stack entries per lane kept in LDS
 constexpr int kMinLdsStack = 4;    // smallest LDS part of any kernel variant (sizes the global spill slab)
 constexpr int kMaxGridBlocks = 2048;   // 256 CUs x 8 resident workgroups
+constexpr int kPipeline = 4;       // render passes in flight at most (one stream and one set of path state each)
 
 // Device buffer that frees itself.
 struct DevBuf {
@@ -53,7 +54,11 @@ struct rtx_ctx {
     rtx::DevBuf b_film, b_tile_samples;
     int spp = 0;
     uint32_t tiles_x = 0, tiles_y = 0;
-    rtx::WavefrontBuffers* wf = nullptr;
+    rtx::WavefrontBuffers* wf[rtx::kPipeline] = {};   // path state of the passes in flight; [0] always exists once a camera is set
+    int pipeline = 3;                                  // passes rtx_render_passes keeps in flight (RTX_PIPELINE); 3 + the caller's stream fit the 4 hardware queues
+    int spill_lanes = 1;                               // traversal-stack slabs in b_spill
+    hipStream_t pipe_stream[rtx::kPipeline] = {};
+    hipEvent_t pipe_film[rtx::kPipeline] = {}, pipe_done[rtx::kPipeline] = {}, ev_fork = nullptr, ev_tiles = nullptr;
 
     rtx_stats stats{};
 };

@@ -40,7 +40,7 @@ int dyn_grid_for(const rtx_ctx* c, size_t n) { return (int)std::min<size_t>((n +
 
 int ensure_spill(rtx_ctx* c)
 {
-    size_t bytes = std::max<size_t>((size_t)c->spill_entries * kMaxGridBlocks * kBlock * sizeof(uint2), 16);
+    size_t bytes = std::max<size_t>((size_t)c->spill_lanes * c->spill_entries * kMaxGridBlocks * kBlock * sizeof(uint2), 16);
     HIP_TRY(c->b_spill.ensure(bytes));
     return RTX_OK;
 }
@@ -76,6 +76,14 @@ int rtx_create(rtx_ctx** out, int device)
     }
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_tiles, hipEventDisableTiming));
+    for (int i = 0; i < kPipeline; i++) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->pipe_stream[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->pipe_film[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->pipe_done[i], hipEventDisableTiming));
+    }
+    if (const char* v = getenv("RTX_PIPELINE")) c->pipeline = std::max(1, std::min(kPipeline, atoi(v)));
     HIP_TRY(c->b_counters.ensure(4 * (1 + 2) * kWorkSlotWords));   // instrumentation counters, then the work-counter slots of the closest-hit and visibility launches
     // RayTracer's defaults, RTBase/Settings.h:40-61
     rtx_settings& s = c->settings;
@@ -93,6 +101,13 @@ void rtx_destroy(rtx_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     wavefront_release(c);
+    for (int i = 0; i < kPipeline; i++) {
+        if (c->pipe_stream[i]) (void)hipStreamDestroy(c->pipe_stream[i]);
+        if (c->pipe_film[i]) (void)hipEventDestroy(c->pipe_film[i]);
+        if (c->pipe_done[i]) (void)hipEventDestroy(c->pipe_done[i]);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_tiles) (void)hipEventDestroy(c->ev_tiles);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -223,9 +238,37 @@ int rtx_render_passes(rtx_ctx* c, int n)
     CTX_TRY(c);
     if (!c->have_scene || !c->have_camera) return fail(RTX_ERR_STATE, "scene and camera must be set before rendering");
     if (n < 0) return fail(RTX_ERR_INVALID, "negative pass count");
+    // Up to c->pipeline passes are in flight, each on a stream and a set of path state of its
+    // own: late bounces hold few rays and a launch then lasts as long as its slowest ray, so
+    // the passes fill each other's idle lanes. The film is still summed in pass order.
+    const int lanes = std::max(1, std::min(n, c->pipeline));
+    if (lanes == 1) {
+        for (int i = 0; i < n; i++) {
+            int rc = wavefront_render_pass(c, 0, c->stream, nullptr, nullptr);
+            if (rc) return fail(rc, "render pass failed: %s", hipGetErrorString(hipGetLastError()));
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return RTX_OK;
+    }
+    for (int l = 1; l < lanes; l++)
+        if (!c->wf[l]) { int rc = wavefront_alloc(c, l); if (rc) return fail(rc, "wavefront buffers: allocation failed"); }
+    if (c->spill_lanes < lanes) { c->spill_lanes = lanes; int rc = ensure_spill(c); if (rc) return rc; }
+    HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+    for (int l = 0; l < lanes; l++) HIP_TRY(hipStreamWaitEvent(c->pipe_stream[l], c->ev_fork, 0));
+    const rtx_settings& st = c->settings;
     for (int i = 0; i < n; i++) {
-        int rc = wavefront_render_pass(c);
+        const int l = i % lanes;
+        int rc = wavefront_render_pass(c, l, c->pipe_stream[l], i > 0 ? c->pipe_film[(i - 1) % lanes] : nullptr, c->pipe_film[l]);
         if (rc) return fail(rc, "render pass failed: %s", hipGetErrorString(hipGetLastError()));
+        if (c->spp == (int)st.init_spp && st.algorithm != RTX_AL_LIGHT_TRACE && st.shard_mode != 2) {
+            // the adaptive sample targets were just computed on this lane: later passes read them
+            HIP_TRY(hipEventRecord(c->ev_tiles, c->pipe_stream[l]));
+            for (int k = 0; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(c->pipe_stream[k], c->ev_tiles, 0));
+        }
+    }
+    for (int l = 0; l < lanes; l++) {
+        HIP_TRY(hipEventRecord(c->pipe_done[l], c->pipe_stream[l]));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->pipe_done[l], 0));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RTX_OK;
@@ -273,7 +316,7 @@ int rtx_update_tile_samples(rtx_ctx* c)
 {
     CTX_TRY(c);
     if (!c->have_camera) return fail(RTX_ERR_STATE, "no camera set");
-    int rc = wavefront_tile_samples(c);
+    int rc = wavefront_tile_samples(c, c->stream);
     if (rc) return fail(rc, "tile statistics kernel failed");
     return RTX_OK;
 }

@@ -644,12 +644,13 @@ __global__ __launch_bounds__(kBlock) void k_tile_samples(WfPtrs w, int spp, uint
 
 // ---- host side --------------------------------------------------------------------------------
 
-inline void wavefront_release(rtx_ctx* c) { delete c->wf; c->wf = nullptr; }
+inline void wavefront_release(rtx_ctx* c) { for (auto& wf : c->wf) { delete wf; wf = nullptr; } }
 
-inline int wavefront_resize(rtx_ctx* c)
+// Path state of pipeline lane `lane` for the current camera
+inline int wavefront_alloc(rtx_ctx* c, int lane)
 {
-    if (!c->wf) c->wf = new WavefrontBuffers;
-    WavefrontBuffers& b = *c->wf;
+    if (!c->wf[lane]) c->wf[lane] = new WavefrontBuffers;
+    WavefrontBuffers& b = *c->wf[lane];
     const size_t P = (size_t)c->tiles_x * c->tiles_y * 256;
 #define RTX_ENS(buf, bytes) do { if ((buf).ensure(bytes) != hipSuccess) return RTX_ERR_NOMEM; } while (0)
     RTX_ENS(b.ray, P * sizeof(rtx_ray)); RTX_ENS(b.hit, P * sizeof(rtx_hit)); RTX_ENS(b.T, P * 12); RTX_ENS(b.L, P * 12);
@@ -665,27 +666,40 @@ inline int wavefront_resize(rtx_ctx* c)
     p.vpl_total = b.vpl_total.as<uint32_t>(); p.tile_off = b.tile_off.as<uint32_t>();
     p.film = c->b_film.as<float>(); p.tile_samples = c->b_tile_samples.as<uint32_t>();
     p.P = (uint32_t)P; p.W = (uint32_t)c->cam.width; p.H = (uint32_t)c->cam.height; p.tiles_x = c->tiles_x; p.n_tiles = c->tiles_x * c->tiles_y;
+    return RTX_OK;
+}
+
+// New camera / film size: lane 0 is rebuilt, the other lanes are dropped until a call needs them
+inline int wavefront_resize(rtx_ctx* c)
+{
+    for (int i = 1; i < kPipeline; i++) { delete c->wf[i]; c->wf[i] = nullptr; }
+    int rc = wavefront_alloc(c, 0);
+    if (rc) return rc;
     // tileSamples.resize(totalTiles, 1), RTBase/Renderer.h:112
-    std::vector<uint32_t> ones(p.n_tiles, 1u);
+    std::vector<uint32_t> ones(c->wf[0]->p.n_tiles, 1u);
     if (hipMemcpy(c->b_tile_samples.p, ones.data(), ones.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return RTX_ERR_HIP;
     return RTX_OK;
 }
 
-inline int wavefront_tile_samples(rtx_ctx* c)
+inline int wavefront_tile_samples(rtx_ctx* c, hipStream_t stream)
 {
-    if (!c->wf) return RTX_ERR_STATE;
-    WfPtrs& w = c->wf->p;
-    hipLaunchKernelGGL(k_tile_samples, dim3((w.n_tiles + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, w, c->spp, c->settings.total_spp);
+    if (!c->wf[0]) return RTX_ERR_STATE;
+    WfPtrs& w = c->wf[0]->p;
+    hipLaunchKernelGGL(k_tile_samples, dim3((w.n_tiles + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, w, c->spp, c->settings.total_spp);
     return hipGetLastError() == hipSuccess ? RTX_OK : RTX_ERR_HIP;
 }
 
-inline int wavefront_render_pass(rtx_ctx* c)
+// One pass on pipeline lane `lane`, enqueued on stream s. Film sums of consecutive passes are
+// kept in pass order (float addition does not commute bit for bit): the pass waits for
+// film_wait before it touches the film and records film_signal when it has.
+inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t film_wait, hipEvent_t film_signal)
 {
-    if (!c->wf) return RTX_ERR_STATE;
-    WavefrontBuffers& b = *c->wf; WfPtrs& w = b.p; const rtx_settings& st = c->settings; hipStream_t s = c->stream;
+    if (!c->wf[lane]) return RTX_ERR_STATE;
+    WavefrontBuffers& b = *c->wf[lane]; WfPtrs& w = b.p; const rtx_settings& st = c->settings;
     const dim3 blk(kBlock), gridP((w.P + kBlock - 1) / kBlock), gridQ(std::min<uint32_t>((w.P + kBlock - 1) / kBlock, kMaxGridBlocks)),
                gridT(std::min<uint32_t>((w.P + kBlock - 1) / kBlock, (uint32_t)c->resident_blocks));   // traversal kernels fetch work dynamically
-    uint2* spill = c->b_spill.as<uint2>(); const uint32_t sstride = kMaxGridBlocks * kBlock;
+    const uint32_t sstride = kMaxGridBlocks * kBlock;
+    uint2* spill = c->b_spill.as<uint2>() + (size_t)lane * c->spill_entries * sstride;
 
     c->spp++;                                            // Film::incrementSPP, RTBase/Imaging.h:403
     PassParams pp; pp.st = st; pp.spp = c->spp; pp.depth = 0;
@@ -705,6 +719,7 @@ inline int wavefront_render_pass(rtx_ctx* c)
         closest(w.qa, 0);
         hipLaunchKernelGGL(k_dm_shade, gridQ, blk, 0, s, w, c->dscene, pp);
         hipLaunchKernelGGL(k_shadow_accumulate, gridT, blk, 0, s, w, c->dscene, (uint32_t)kShadowCounterBase, (uint32_t)kShadowWorkBase, spill, sstride);
+        if (film_wait && hipStreamWaitEvent(s, film_wait, 0) != hipSuccess) return RTX_ERR_HIP;
         hipLaunchKernelGGL(k_film_accumulate, gridP, blk, 0, s, w, (int)st.filter);
         c->stats.samples += (uint64_t)w.W * w.H;
     } else if (st.algorithm == RTX_AL_PATH_TRACE) {
@@ -718,6 +733,7 @@ inline int wavefront_render_pass(rtx_ctx* c)
             hipLaunchKernelGGL(k_shadow_accumulate, gridT, blk, 0, s, w, c->dscene, (uint32_t)(kShadowCounterBase + d), (uint32_t)(kShadowWorkBase + d * kWorkSlotWords), spill, sstride);
             std::swap(qin, qout);
         }
+        if (film_wait && hipStreamWaitEvent(s, film_wait, 0) != hipSuccess) return RTX_ERR_HIP;
         hipLaunchKernelGGL(k_film_accumulate, gridP, blk, 0, s, w, (int)st.filter);
         c->stats.samples += (uint64_t)w.W * w.H;
     } else if (st.algorithm == RTX_AL_LIGHT_TRACE) {
@@ -758,12 +774,17 @@ inline int wavefront_render_pass(rtx_ctx* c)
         hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
         closest(w.qa, 0);
         hipLaunchKernelGGL(k_ir_gather, gridQ, blk, 0, s, w, c->dscene, pp, spill, sstride);
+        if (film_wait && hipStreamWaitEvent(s, film_wait, 0) != hipSuccess) return RTX_ERR_HIP;
         hipLaunchKernelGGL(k_film_accumulate, gridP, blk, 0, s, w, (int)st.filter);
         c->stats.samples += (uint64_t)w.W * w.H;
     }
     if (hipGetLastError() != hipSuccess) return RTX_ERR_HIP;
     // RTBase/Renderer.h:780-781
-    if (c->spp == (int)st.init_spp && st.algorithm != RTX_AL_LIGHT_TRACE && st.shard_mode != 2) return wavefront_tile_samples(c);
+    if (c->spp == (int)st.init_spp && st.algorithm != RTX_AL_LIGHT_TRACE && st.shard_mode != 2) {
+        int rc = wavefront_tile_samples(c, s);
+        if (rc) return rc;
+    }
+    if (film_signal && hipEventRecord(film_signal, s) != hipSuccess) return RTX_ERR_HIP;
     return RTX_OK;
 }
 
