@@ -342,6 +342,9 @@ class Core:
         self._check(self.lib.rtx_get_stats(self.ctx, C.byref(s)))
         return s
 
+    def reset_stats(self):
+        self._check(self.lib.rtx_reset_stats(self.ctx))
+
     def timer_begin(self):
         self._check(self.lib.rtx_timer_begin(self.ctx))
 

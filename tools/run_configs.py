@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Full-size runs of the benchmark configurations other than the headline closest-hit one,
+on one GPU: path tracing of the Cornell stand-in (with the CPU oracle's renderMT beside it),
+the mixed-material scene at 1080p, the ~10 M-triangle terrain at 4K (whole film and the
+tile share of rank 0 of 2), adaptive sampling, light tracing and instant radiosity.
+Prints one JSON object per configuration; `--out file` also writes them as a JSON list.
+
+    python tools/run_configs.py [--quick] [--out gpurun_out/configs.json]
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true", help="fewer passes and a 1 M-triangle terrain")
+    ap.add_argument("--out", default="")
+    ap.add_argument("--only", default="", help="comma list of configuration names to run")
+    args = ap.parse_args()
+    pkg = importlib.import_module("ray-tracer_amd")
+    scenes = importlib.import_module("ray-tracer_amd.scenes")
+    lib = pkg.load_library()
+    core = pkg.Core(0, lib)
+    results = []
+    only = set(x for x in args.only.split(",") if x)
+
+    def timed(name, scene, cam_kw, w, h, passes, settings, note="", warm=2, extra=None):
+        if only and name not in only:
+            return None
+        t0 = time.perf_counter()
+        core.upload_scene(scene)
+        t_up = time.perf_counter() - t0
+        cam = pkg.look_at(lib, width=w, height=h, **cam_kw)
+        core.set_camera(cam)
+        core.set_settings(settings)
+        core.clear()
+        core.render_passes(warm)
+        core.clear()
+        core.reset_stats()
+        t0 = time.perf_counter()
+        core.render_passes(passes)
+        dt = time.perf_counter() - t0
+        st = core.stats()
+        film, spp, tiles = core.film()
+        r = {"config": name, "triangles": int(scene.n_triangles), "resolution": [w, h], "passes": passes,
+             "spp_per_s": round(passes / dt, 3), "ms_per_pass": round(dt / passes * 1e3, 3),
+             "msamples_per_s": round(st.samples / dt / 1e6, 2), "scene_upload_s": round(t_up, 2),
+             "film_mean": float(film.mean() / max(spp, 1)), "note": note}
+        if extra:
+            r.update(extra(film, spp, tiles))
+        results.append(r)
+        print(json.dumps(r), flush=True)
+        return r
+
+    q = args.quick
+    # configs[0]: Cornell stand-in, path trace, 64 spp, 5 bounces, MIS on
+    cornell = scenes.cornell_box("diffuse")
+    st = pkg.make_settings(total_spp=64, max_bounces=5, use_mis=1)
+    r = timed("cornell_pt_64spp", cornell, scenes.cornell_camera(), 1024, 1024, 16 if q else 64, st,
+              "stand-in for Ray-Tracer-Scenes scene 0 (asset not available offline)")
+    if r is not None:
+        pyoracle = importlib.import_module("oracle.pyoracle")
+        orc = pyoracle.Oracle(pkg)
+        threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 8, 16)
+        osc = orc.scene(cornell)
+        osc.set_camera(pkg.look_at(lib, width=1024, height=1024, **scenes.cornell_camera()))
+        ren = osc.renderer(st, threads=threads, counter_rng=False)     # the reference's MT19937 streams, renderMT
+        n_cpu = 1 if q else 2
+        t0 = time.perf_counter()
+        ren.render_passes(n_cpu)
+        dt = time.perf_counter() - t0
+        ren.close(); osc.close()
+        r["cpu_oracle_spp_per_s"] = round(n_cpu / dt, 4)
+        r["cpu_threads"] = threads
+        print(json.dumps({"config": "cornell_pt_64spp", "cpu_oracle_spp_per_s": r["cpu_oracle_spp_per_s"], "cpu_threads": threads}), flush=True)
+
+    # configs[2]: mixed materials + env-map MIS, 1080p, 256 spp
+    mixed = scenes.mixed_scene(128)
+    timed("mixed_env_mis_1080p", mixed, scenes.mixed_camera(), 1920, 1080, 32 if q else 256,
+          pkg.make_settings(total_spp=256, max_bounces=5, use_mis=1))
+
+    # configs[4]: adaptive sampling, light tracing, instant radiosity on the mixed scene
+    def tile_stats(film, spp, tiles):
+        return {"tile_target_min": int(tiles.min()), "tile_target_max": int(tiles.max()), "tile_target_mean": float(tiles.mean())}
+    timed("mixed_adaptive_10_256", mixed, scenes.mixed_camera(), 1920, 1080, 32 if q else 256,
+          pkg.make_settings(total_spp=256, init_spp=10, adaptive_sampling=1, max_bounces=5), extra=tile_stats)
+    timed("mixed_light_trace", mixed, scenes.mixed_camera(), 1920, 1080, 16 if q else 64,
+          pkg.make_settings(algorithm=pkg.AL_LIGHT_TRACE, total_spp=64, max_bounces=5))
+    # 22 light paths x up to 6 vertices: ~128 VPLs per pass
+    timed("mixed_instant_radiosity", mixed, scenes.mixed_camera(), 1920, 1080, 2 if q else 8,
+          pkg.make_settings(algorithm=pkg.AL_INSTANT_RADIOSITY, total_spp=8, max_bounces=5, vpl_rays_per_tile=1, num_threads=22), warm=1)
+
+    # configs[3]: ~10 M triangles at 4K; whole film, then the tiles of rank 0 of 2
+    terr = scenes.terrain(707 if q else 2236)
+    timed("terrain_4k_pt", terr, scenes.terrain_camera(), 3840, 2160, 4 if q else 16, pkg.make_settings(total_spp=16, max_bounces=5), warm=1)
+    timed("terrain_4k_pt_tiles_rank0_of_2", terr, scenes.terrain_camera(), 3840, 2160, 4 if q else 16,
+          pkg.make_settings(total_spp=16, max_bounces=5, shard_mode=1, shard_rank=0, shard_world=2), warm=1,
+          note="one rank's share under tile sharding (tiles t % 2 == 0)")
+
+    if args.out:
+        with open(args.out, "w") as f:
+            json.dump(results, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
