@@ -54,7 +54,12 @@ enum {
     RTX_BSDF_MIRROR    = 1, /* MirrorBSDF    Materials.h:179 */
     RTX_BSDF_CONDUCTOR = 2, /* ConductorBSDF Materials.h:234 ("Glossy") */
     RTX_BSDF_GLASS     = 3, /* GlassBSDF     Materials.h:351 */
-    RTX_BSDF_PLASTIC   = 4  /* PlasticBSDF   Materials.h:564 */
+    RTX_BSDF_PLASTIC   = 4, /* PlasticBSDF   Materials.h:564 */
+    RTX_BSDF_DIELECTRIC = 5, /* DielectricBSDF Materials.h:436: cosine lobe, one-sided (the reference's placeholder body) */
+    RTX_BSDF_ORENNAYAR = 6, /* OrenNayarBSDF Materials.h:485, sigma passed in `roughness` */
+    /* LayeredBSDF Materials.h:680 forwards everything to its base BSDF but reports isTwoSided() = true:
+     * describe it as (base type | RTX_BSDF_LAYERED) with the base's parameters */
+    RTX_BSDF_LAYERED   = 0x100
 };
 
 /* One material. `roughness` is the constructor argument of the reference classes

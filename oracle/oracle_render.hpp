@@ -90,15 +90,22 @@ struct BSDF {                                                     // BSDF + subc
     int type = RTX_BSDF_DIFFUSE; const Texture* albedo = nullptr; RGB emission;
     RGB eta, k; float alpha = 0;        // conductor (eta,k) / plastic (alpha)
     float intIOR = 1, extIOR = 1, etaD = 1, invEta = 1, e = 0;  // glass / plastic
+    float onA = 0, onB = 0;             // Oren-Nayar, Materials.h:491
+    bool layered = false;               // wrapped in a LayeredBSDF, Materials.h:680-724 (pass-through, two-sided)
 
     static const RGB alEta() { return rgb(1.5f, 0.9f, 0.6f); }   // Aluminium_Eta, Materials.h:37
     static const RGB alK() { return rgb(7.0f, 6.0f, 4.7f); }     // Aluminium_K, Materials.h:42
 
     void init(const rtx_material& m, const Texture* tex)
     {
-        type = m.type; albedo = tex; emission = rgb(m.emission[0], m.emission[1], m.emission[2]);
+        type = m.type & ~RTX_BSDF_LAYERED; layered = (m.type & RTX_BSDF_LAYERED) != 0; albedo = tex; emission = rgb(m.emission[0], m.emission[1], m.emission[2]);
         eta = rgb(m.eta[0], m.eta[1], m.eta[2]); k = rgb(m.k[0], m.k[1], m.k[2]);
         intIOR = m.int_ior; extIOR = m.ext_ior;
+        if (type == RTX_BSDF_ORENNAYAR) {                                            // Materials.h:495-502
+            const float sigma = m.roughness;
+            onA = 1.0f - (sigma * sigma / (2.0f * ((sigma * sigma) + 0.33f)));
+            onB = (0.45 * sigma * sigma) / (sigma * sigma + 0.09f);
+        }
         if (type == RTX_BSDF_CONDUCTOR) alpha = 1.62142f * sqrtf(m.roughness);      // Materials.h:248
         if (type == RTX_BSDF_GLASS) { etaD = extIOR / intIOR; invEta = 1.0f / etaD; } // Materials.h:368-369
         if (type == RTX_BSDF_PLASTIC) {                                              // Materials.h:582-585
@@ -111,16 +118,37 @@ struct BSDF {                                                     // BSDF + subc
     bool isLight() const { return lum(emission) > 0 ? true : false; }               // Materials.h:123
     RGB emit() const { return emission; }                                           // Materials.h:131
     bool isPureSpecular() const { return type == RTX_BSDF_MIRROR || type == RTX_BSDF_GLASS; } // :165,219,335,420,664
-    bool isTwoSided() const { return type != RTX_BSDF_GLASS; }                      // :169,223,340,425,669
+    bool isTwoSided() const { return layered || (type != RTX_BSDF_GLASS && type != RTX_BSDF_DIELECTRIC); } // :169,223,340,425,475,553,669,716
+    static float sphericalTheta(V3 w) { return acosf(w.z); }                        // Core.h:564-567
+    static float sphericalPhi(V3 w) { float p = atan2f(w.y, w.x); return (p < 0.0f) ? p + (2.0f * kPi) : p; }   // Core.h:568-572
+    float orenNayarTerm(float thetaI, float phiI, float thetaO, float phiO) const   // Materials.h:517,536
+    {
+        return (onA + onB * std::max(cosf(phiI - phiO), 0.0f) * sinf(std::max(thetaI, thetaO) * tanf(std::min(thetaI, thetaO))));
+    }
 
     V3 sample(const Shading& sd, Sampler* s, RGB& col, float& pdf) const
     {
         switch (type) {
+        case RTX_BSDF_DIELECTRIC:                                                   // Materials.h:451-459 (same body)
         case RTX_BSDF_DIFFUSE: {                                                    // Materials.h:148-154
             ORC_DRAW_R2_THEN_R1(s, r1, r2);
             V3 wi = cosineSampleHemisphere(r1, r2);
             pdf = (float)(wi.z / kPi);
             col = albedo->sample(sd.tu, sd.tv) / (float)kPi;
+            return sd.frame.toWorld(wi);
+        }
+        case RTX_BSDF_ORENNAYAR: {                                                  // Materials.h:504-523
+            V3 localWo = sd.frame.toLocal(sd.wo);
+            float thetaO = sphericalTheta(localWo);
+            float phiO = sphericalPhi(localWo);
+            float r1 = sqrtf(s->next());
+            float thetaI = acosf(r1);
+            float phiI = kPi * 2 * s->next();
+            float sinTheta = sinf(thetaI);
+            V3 wi = v3(sinTheta * cosf(phiI), sinTheta * sinf(phiI), r1);
+            float demon = orenNayarTerm(thetaI, phiI, thetaO, phiO);
+            pdf = (float)(fabsf(wi.z) / kPi);
+            col = (albedo->sample(sd.tu, sd.tv) / (float)kPi) * demon;
             return sd.frame.toWorld(wi);
         }
         case RTX_BSDF_MIRROR: {                                                     // Materials.h:193-208
@@ -205,7 +233,15 @@ struct BSDF {                                                     // BSDF + subc
     RGB evaluate(const Shading& sd, V3 wi) const
     {
         switch (type) {
+        case RTX_BSDF_DIELECTRIC:                                                                      // Materials.h:460-464
         case RTX_BSDF_DIFFUSE: return albedo->sample(sd.tu, sd.tv) / (float)kPi;                      // Materials.h:155-158
+        case RTX_BSDF_ORENNAYAR: {                                                                     // Materials.h:525-539
+            V3 localWo = sd.frame.toLocal(sd.wo), localWi = sd.frame.toLocal(wi);
+            float thetaO = sphericalTheta(localWo), phiO = sphericalPhi(localWo);
+            float thetaI = sphericalTheta(localWi), phiI = sphericalPhi(localWi);
+            float demon = orenNayarTerm(thetaI, phiI, thetaO, phiO);
+            return (albedo->sample(sd.tu, sd.tv) / (float)kPi) * demon;
+        }
         case RTX_BSDF_MIRROR: return albedo->sample(sd.tu, sd.tv) / fabsf(sd.frame.toLocal(wi).z);     // Materials.h:209-213
         case RTX_BSDF_CONDUCTOR: {                                                                     // Materials.h:300-318
             if (alpha < kEps) return albedo->sample(sd.tu, sd.tv) / fabsf(sd.frame.toLocal(wi).z);
@@ -233,6 +269,8 @@ struct BSDF {                                                     // BSDF + subc
     {
         switch (type) {
         case RTX_BSDF_DIFFUSE: return (float)(sd.frame.toLocal(wi).z / kPi);                          // Materials.h:159-164
+        case RTX_BSDF_DIELECTRIC:                                                                      // Materials.h:465-470
+        case RTX_BSDF_ORENNAYAR: return cosineHemispherePDF(sd.frame.toLocal(wi));                    // Materials.h:541-546
         case RTX_BSDF_MIRROR: return 0.0f;                                                             // Materials.h:214-218
         case RTX_BSDF_CONDUCTOR: {                                                                     // Materials.h:320-333
             if (alpha < kEps) return 0.0f;

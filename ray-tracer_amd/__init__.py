@@ -20,7 +20,8 @@ LIB_PATH = os.path.join(_HERE, "librtx.so")
 AL_PATH_TRACE, AL_LIGHT_TRACE, AL_INSTANT_RADIOSITY = 0, 1, 2
 DM_ALGORITHM, DM_NORMALS, DM_ALBEDO, DM_DIRECT = 0, 1, 2, 3
 FT_BOX, FT_GAUSSIAN, FT_MITCHELL_NETRAVALI = 0, 1, 2
-BSDF_DIFFUSE, BSDF_MIRROR, BSDF_CONDUCTOR, BSDF_GLASS, BSDF_PLASTIC = 0, 1, 2, 3, 4
+BSDF_DIFFUSE, BSDF_MIRROR, BSDF_CONDUCTOR, BSDF_GLASS, BSDF_PLASTIC, BSDF_DIELECTRIC, BSDF_ORENNAYAR = 0, 1, 2, 3, 4, 5, 6
+BSDF_LAYERED = 0x100   # OR-ed onto the base type: LayeredBSDF forwards to its base but is two-sided
 
 RAY_DTYPE = np.dtype([("o", np.float32, 3), ("d", np.float32, 3)])
 HIT_DTYPE = np.dtype([("id", np.uint32), ("t", np.float32), ("alpha", np.float32),

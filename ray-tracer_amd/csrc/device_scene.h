@@ -35,12 +35,13 @@ struct MaterialDev {
     float emission[3];
     int32_t is_light;            // BSDF::isLight, Materials.h:123
     float eta[3];
-    float alpha;                 // 1.62142*sqrt(roughness), Materials.h:248,582
+    float alpha;                 // 1.62142*sqrt(roughness), Materials.h:248,582; Oren-Nayar: A, Materials.h:500
     float k[3];
     float eta_d;                 // extIOR/intIOR, Materials.h:368,584
     float inv_eta;               // Materials.h:369
     float phong_e;               // Materials.h:585
-    float pad[2];
+    int32_t two_sided;           // BSDF::isTwoSided
+    float on_b;                  // Oren-Nayar B, Materials.h:501
 };
 
 // One emitter of Scene::lights (RTBase/Scene.h:83): kind 0 = area triangle, 1 = constant

@@ -100,7 +100,8 @@ std::string prepare_scene(const rtx_scene_desc& d, HostScene& hs)
         if (d.textures[i].width < 1 || d.textures[i].height < 1 || !d.textures[i].rgb) return "bad texture";
     for (uint32_t i = 0; i < d.n_materials; i++) {
         if (d.materials[i].texture < 0 || (uint32_t)d.materials[i].texture >= d.n_textures) return "material texture index out of range";
-        if (d.materials[i].type < RTX_BSDF_DIFFUSE || d.materials[i].type > RTX_BSDF_PLASTIC) return "unknown BSDF type";
+        const int base = d.materials[i].type & ~RTX_BSDF_LAYERED;
+        if (base < RTX_BSDF_DIFFUSE || base > RTX_BSDF_ORENNAYAR) return "unknown BSDF type";
     }
     for (uint64_t i = 0; i < d.n_triangles; i++) if (d.material_index[i] >= d.n_materials) return "triangle material index out of range";
     if (d.env_rgb && (d.env_width < 2 || d.env_height < 2)) return "environment map must be at least 2x2";
@@ -119,13 +120,20 @@ std::string prepare_scene(const rtx_scene_desc& d, HostScene& hs)
     hs.materials.assign(d.n_materials, MaterialDev{});
     for (uint32_t i = 0; i < d.n_materials; i++) {
         const rtx_material& m = d.materials[i]; MaterialDev& o = hs.materials[i];
-        o.type = m.type; o.tex_offset = texOffset[m.texture]; o.tex_w = d.textures[m.texture].width; o.tex_h = d.textures[m.texture].height;
+        o.type = m.type & ~RTX_BSDF_LAYERED; o.tex_offset = texOffset[m.texture]; o.tex_w = d.textures[m.texture].width; o.tex_h = d.textures[m.texture].height;
         for (int k = 0; k < 3; k++) { o.emission[k] = m.emission[k]; o.eta[k] = m.eta[k]; o.k[k] = m.k[k]; }
         o.is_light = lumf(m.emission) > 0 ? 1 : 0;                                                 // Materials.h:123-126
-        o.alpha = 0; o.eta_d = 1; o.inv_eta = 1; o.phong_e = 0;
-        if (m.type == RTX_BSDF_CONDUCTOR) o.alpha = 1.62142f * sqrtf(m.roughness);                // Materials.h:248
-        if (m.type == RTX_BSDF_GLASS) { o.eta_d = m.ext_ior / m.int_ior; o.inv_eta = 1.0f / o.eta_d; } // Materials.h:368-369
-        if (m.type == RTX_BSDF_PLASTIC) {                                                          // Materials.h:582-585
+        o.alpha = 0; o.eta_d = 1; o.inv_eta = 1; o.phong_e = 0; o.on_b = 0;
+        // isTwoSided: false for Glass (Materials.h:425) and Dielectric (:475), true otherwise and for any LayeredBSDF (:716)
+        o.two_sided = ((m.type & RTX_BSDF_LAYERED) || (o.type != RTX_BSDF_GLASS && o.type != RTX_BSDF_DIELECTRIC)) ? 1 : 0;
+        if (o.type == RTX_BSDF_ORENNAYAR) {                                                        // Materials.h:500-501
+            const float sigma = m.roughness;
+            o.alpha = 1.0f - (sigma * sigma / (2.0f * ((sigma * sigma) + 0.33f)));
+            o.on_b = (float)((0.45 * sigma * sigma) / (sigma * sigma + 0.09f));
+        }
+        if (o.type == RTX_BSDF_CONDUCTOR) o.alpha = 1.62142f * sqrtf(m.roughness);                // Materials.h:248
+        if (o.type == RTX_BSDF_GLASS) { o.eta_d = m.ext_ior / m.int_ior; o.inv_eta = 1.0f / o.eta_d; } // Materials.h:368-369
+        if (o.type == RTX_BSDF_PLASTIC) {                                                          // Materials.h:582-585
             o.alpha = 1.62142f * sqrtf(m.roughness);
             o.eta_d = m.ext_ior / m.int_ior;
             float a = o.alpha > 0.001f ? o.alpha : 0.001f;   // std::max(alpha, 0.001f)

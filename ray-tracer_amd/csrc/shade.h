@@ -156,13 +156,26 @@ RTX_DI float Dggx(V3 h, float alpha)
 }
 
 RTX_DI bool isPureSpecular(const MaterialDev& m) { return m.type == RTX_BSDF_MIRROR || m.type == RTX_BSDF_GLASS; } // Materials.h:219,420
-RTX_DI bool isTwoSided(const MaterialDev& m) { return m.type != RTX_BSDF_GLASS; }                                   // Materials.h:425
+RTX_DI bool isTwoSided(const MaterialDev& m) { return m.two_sided != 0; }                                           // Materials.h:169,425,475,553,716
 
-// BSDF::sample of the five classes, RTBase/Materials.h:148,193,251,372,588
+// SphericalCoordinates, RTBase/Core.h:564-572
+RTX_DI float sphericalTheta(V3 w) { return acosf(w.z); }
+RTX_DI float sphericalPhi(V3 w) { float p = atan2f(w.y, w.x); return (p < 0.0f) ? (float)(p + (2.0f * kPiD)) : p; }
+// the angular factor of OrenNayarBSDF, Materials.h:517,536, as written there
+RTX_DI float orenNayarTerm(const MaterialDev& m, float thetaI, float phiI, float thetaO, float phiO)
+{
+    float c = cosf(phiI - phiO);
+    float cpos = (c < 0.0f) ? 0.0f : c;                    // std::max(c, 0.0f)
+    float hi = (thetaI < thetaO) ? thetaO : thetaI;        // std::max(thetaI, thetaO)
+    float lo = (thetaO < thetaI) ? thetaO : thetaI;        // std::min(thetaI, thetaO)
+    return (m.alpha + m.on_b * cpos * sinf(hi * tanf(lo)));
+}
+
+// BSDF::sample, RTBase/Materials.h:148,193,251,372,451,504,588
 RTX_DI V3 bsdf_sample(const DeviceScene& sc, const Shading& sd, Rng& rng, C3& col, float& pdf)
 {
     const MaterialDev& m = *sd.mat;
-    if (m.type == RTX_BSDF_DIFFUSE) {
+    if (m.type == RTX_BSDF_DIFFUSE || m.type == RTX_BSDF_DIELECTRIC) {
         RTX_DRAW_R2_THEN_R1(rng, r1, r2);
         V3 wi = cosineSampleHemisphere(r1, r2);
         pdf = (float)(wi.z / kPiD);
@@ -170,6 +183,18 @@ RTX_DI V3 bsdf_sample(const DeviceScene& sc, const Shading& sd, Rng& rng, C3& co
         return sd.frame.toWorld(wi);
     }
     V3 lwo = sd.frame.toLocal(sd.wo);
+    if (m.type == RTX_BSDF_ORENNAYAR) {
+        float thetaO = sphericalTheta(lwo), phiO = sphericalPhi(lwo);
+        float r1 = sqrtf(rng.next());
+        float thetaI = acosf(r1);
+        float phiI = (float)(kPiD * 2 * rng.next());
+        float sinTheta = sinf(thetaI);
+        V3 wi = mk(sinTheta * cosf(phiI), sinTheta * sinf(phiI), r1);
+        float demon = orenNayarTerm(m, thetaI, phiI, thetaO, phiO);
+        pdf = (float)(fabsf(wi.z) / kPiD);
+        col = (albedo(sc, sd) / (float)kPiD) * demon;
+        return sd.frame.toWorld(wi);
+    }
     if (m.type == RTX_BSDF_MIRROR) {
         V3 wi = mk(-lwo.x, -lwo.y, lwo.z);
         C3 F = fresnelConductor(fabsf(lwo.z), mkc(1.5f, 0.9f, 0.6f), mkc(7.0f, 6.0f, 4.7f));   // Aluminium, Materials.h:37,42
@@ -246,12 +271,17 @@ RTX_DI V3 bsdf_sample(const DeviceScene& sc, const Shading& sd, Rng& rng, C3& co
     return sd.frame.toWorld(wi);
 }
 
-// BSDF::evaluate, RTBase/Materials.h:155,209,300,409,628
+// BSDF::evaluate, RTBase/Materials.h:155,209,300,409,460,525,628
 RTX_DI C3 bsdf_evaluate(const DeviceScene& sc, const Shading& sd, V3 wi)
 {
     const MaterialDev& m = *sd.mat;
-    if (m.type == RTX_BSDF_DIFFUSE) return albedo(sc, sd) / (float)kPiD;
+    if (m.type == RTX_BSDF_DIFFUSE || m.type == RTX_BSDF_DIELECTRIC) return albedo(sc, sd) / (float)kPiD;
     if (m.type == RTX_BSDF_GLASS) return mkc(0, 0, 0);
+    if (m.type == RTX_BSDF_ORENNAYAR) {
+        V3 lo = sd.frame.toLocal(sd.wo), li = sd.frame.toLocal(wi);
+        float demon = orenNayarTerm(m, sphericalTheta(li), sphericalPhi(li), sphericalTheta(lo), sphericalPhi(lo));
+        return (albedo(sc, sd) / (float)kPiD) * demon;
+    }
     if (m.type == RTX_BSDF_MIRROR || (m.type == RTX_BSDF_CONDUCTOR && m.alpha < kEps)) return albedo(sc, sd) / fabsf(sd.frame.toLocal(wi).z);
     V3 lwo = sd.frame.toLocal(sd.wo), lwi = sd.frame.toLocal(wi);
     if (m.type == RTX_BSDF_CONDUCTOR) {
@@ -271,11 +301,12 @@ RTX_DI C3 bsdf_evaluate(const DeviceScene& sc, const Shading& sd, V3 wi)
     return c * (diff + spec);
 }
 
-// BSDF::PDF, RTBase/Materials.h:159,214,320,415,646
+// BSDF::PDF, RTBase/Materials.h:159,214,320,415,465,541,646
 RTX_DI float bsdf_pdf(const Shading& sd, V3 wi)
 {
     const MaterialDev& m = *sd.mat;
     if (m.type == RTX_BSDF_DIFFUSE) return (float)(sd.frame.toLocal(wi).z / kPiD);
+    if (m.type == RTX_BSDF_DIELECTRIC || m.type == RTX_BSDF_ORENNAYAR) return cosineHemispherePDF(sd.frame.toLocal(wi));   // Materials.h:465-470, 541-546
     if (m.type == RTX_BSDF_MIRROR || m.type == RTX_BSDF_GLASS) return 0.0f;
     V3 lwo = sd.frame.toLocal(sd.wo), lwi = sd.frame.toLocal(wi);
     if (m.type == RTX_BSDF_CONDUCTOR) {

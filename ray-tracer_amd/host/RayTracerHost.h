@@ -123,6 +123,30 @@ public:
     PlasticBSDF(Texture* t, float i, float e, float r) : intIOR(i), extIOR(e), roughness(r) { albedo = t; }
     rtx_material describe() const override { rtx_material m = base(RTX_BSDF_PLASTIC); m.int_ior = intIOR; m.ext_ior = extIOR; m.roughness = roughness; return m; }
 };
+class DielectricBSDF : public BSDF {      // Materials.h:436-483 (the reference's body is a cosine lobe; roughness and the IORs are stored, not used)
+public:
+    float intIOR, extIOR, roughness;
+    DielectricBSDF(Texture* t, float i, float e, float r) : intIOR(i), extIOR(e), roughness(r) { albedo = t; }
+    rtx_material describe() const override { rtx_material m = base(RTX_BSDF_DIELECTRIC); m.int_ior = intIOR; m.ext_ior = extIOR; m.roughness = roughness; return m; }
+};
+class OrenNayarBSDF : public BSDF {       // Materials.h:485-562
+public:
+    float sigma;
+    OrenNayarBSDF(Texture* t, float sigma_) : sigma(sigma_) { albedo = t; }
+    rtx_material describe() const override { rtx_material m = base(RTX_BSDF_ORENNAYAR); m.roughness = sigma; return m; }
+};
+class LayeredBSDF : public BSDF {         // Materials.h:680-724: forwards to its base BSDF, two-sided
+public:
+    BSDF* baseBSDF; Colour sigmaa; float thickness, intIOR, extIOR;
+    LayeredBSDF(BSDF* b, Colour sa, float th, float i, float e) : baseBSDF(b), sigmaa(sa), thickness(th), intIOR(i), extIOR(e) { albedo = b->albedo; }
+    rtx_material describe() const override
+    {
+        rtx_material m = baseBSDF->describe();
+        m.type |= RTX_BSDF_LAYERED;
+        m.emission[0] = emission.r; m.emission[1] = emission.g; m.emission[2] = emission.b;   // isLight()/emit() are the wrapper's own
+        return m;
+    }
+};
 
 class Triangle {
 public:

@@ -70,7 +70,9 @@ def cornell_box(materials="diffuse"):
     two boxes, one emissive quad Le = (17, 12, 4), black background.
 
     materials="mixed" swaps the two boxes and the back wall for Mirror / Glass / Plastic /
-    Conductor so that every BSDF of RTBase/Materials.h is exercised in a tiny scene.
+    Conductor so that every BSDF of RTBase/Materials.h is exercised in a tiny scene;
+    materials="next" uses the remaining classes instead: Oren-Nayar walls, a Dielectric tall
+    box, a Layered(Glass) short box and a Layered(Plastic) small box.
     """
     tris, mat = [], []
 
@@ -80,13 +82,14 @@ def cornell_box(materials="diffuse"):
 
     add(_quad((-1, -1, -1), (1, -1, -1), (1, -1, 1), (-1, -1, 1)), 0)      # floor (white)
     add(_quad((-1, 1, 1), (1, 1, 1), (1, 1, -1), (-1, 1, -1)), 0)          # ceiling
-    add(_quad((-1, -1, -1), (-1, 1, -1), (1, 1, -1), (1, -1, -1)), 5 if materials == "mixed" else 0)  # back
+    extra = materials in ("mixed", "next")
+    add(_quad((-1, -1, -1), (-1, 1, -1), (1, 1, -1), (1, -1, -1)), 5 if extra else 0)  # back
     add(_quad((-1, -1, 1), (-1, 1, 1), (-1, 1, -1), (-1, -1, -1)), 1)      # left (red)
     add(_quad((1, -1, -1), (1, 1, -1), (1, 1, 1), (1, -1, 1)), 2)          # right (green)
     add(_quad((-0.25, 0.999, -0.25), (0.25, 0.999, -0.25), (0.25, 0.999, 0.25), (-0.25, 0.999, 0.25)), 3)  # light
-    add(_box((-0.7, -1, -0.6), (-0.1, 0.2, 0.0)), 4 if materials == "mixed" else 0)   # tall box
-    add(_box((0.1, -1, 0.0), (0.7, -0.4, 0.6)), 6 if materials == "mixed" else 0)     # short box
-    if materials == "mixed":
+    add(_box((-0.7, -1, -0.6), (-0.1, 0.2, 0.0)), 4 if extra else 0)   # tall box
+    add(_box((0.1, -1, 0.0), (0.7, -0.4, 0.6)), 6 if extra else 0)     # short box
+    if extra:
         add(_box((-0.2, -1, 0.5), (0.1, -0.7, 0.8)), 7)
     pos = np.array(tris, np.float32)
     nrm = np.repeat(_face_normals(pos)[:, None, :], 3, axis=1)
@@ -100,6 +103,15 @@ def cornell_box(materials="diffuse"):
             material(_pkg.BSDF_PLASTIC, 1, roughness=0.1, int_ior=1.5, ext_ior=1.0),
             material(_pkg.BSDF_GLASS, 3, int_ior=1.5, ext_ior=1.0),
             material(_pkg.BSDF_CONDUCTOR, 3, eta=(0.17, 0.35, 1.5), k=(3.1, 2.7, 1.9), roughness=0.2)]
+    if materials == "next":
+        L = _pkg.BSDF_LAYERED
+        mats = [material(_pkg.BSDF_ORENNAYAR, 0, roughness=0.6), material(_pkg.BSDF_ORENNAYAR, 1, roughness=0.3),
+                material(_pkg.BSDF_ORENNAYAR, 2, roughness=1.0),
+                material(_pkg.BSDF_DIFFUSE, 0, emission=(17, 12, 4)),
+                material(_pkg.BSDF_DIELECTRIC, 3, roughness=0.2, int_ior=1.5, ext_ior=1.0),
+                material(_pkg.BSDF_ORENNAYAR | L, 1, roughness=0.45),
+                material(_pkg.BSDF_GLASS | L, 3, int_ior=1.5, ext_ior=1.0),
+                material(_pkg.BSDF_PLASTIC | L, 2, roughness=0.1, int_ior=1.5, ext_ior=1.0)]
     return SceneArrays(pos, nrm, uv, np.array(mat, np.uint32), mats, tex)
 
 

@@ -46,7 +46,7 @@ def _assert_films_match(got, want, what, frac=OUTLIER_FRACTION):
     assert f <= frac, f"{what}: {f:.4%} of pixels beyond rel {REL_TOL} (median err {np.median(err):.2e})"
 
 
-@pytest.mark.parametrize("materials", ["diffuse", "mixed"])
+@pytest.mark.parametrize("materials", ["diffuse", "mixed", "next"])
 def test_path_trace_per_sample_parity_cornell(pkg, lib, core, orc, scenes, materials):
     st, osc = _setup(pkg, lib, core, orc, scenes.cornell_box(materials), scenes.cornell_camera(), 96, 80, total_spp=3, seed=11)
     r = osc.renderer(st, threads=8, counter_rng=True)

@@ -158,3 +158,70 @@ def test_film_splat_box_filter_and_tile_targets(pkg, orc, scenes):
     r.film_write(np.full((24, 40, 3), 2.0, np.float32), 4)
     r.calculate_tile_samples()
     assert (r.film()[2] == 4).all()
+
+
+def test_oren_nayar_dielectric_and_layered_bsdfs(pkg, orc, scenes):
+    """OrenNayarBSDF / DielectricBSDF / LayeredBSDF (RTBase/Materials.h:436-562, 680-724) against
+    the closed forms written out here in numpy: parity unpinned by the reference's own tests."""
+    sc = scenes.cornell_box("next")
+    osc = orc.scene(sc)
+    rs = np.random.RandomState(5)
+    n = 256
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (n, 1))          # frame = (x, y, z) up to the ONB's choice of tangents
+    wo = rs.normal(size=(n, 3)).astype(np.float32); wo[:, 2] = np.abs(wo[:, 2]) + 0.05; wo /= np.linalg.norm(wo, axis=1, keepdims=True)
+    wi = rs.normal(size=(n, 3)).astype(np.float32); wi[:, 2] = np.abs(wi[:, 2]) + 0.05; wi /= np.linalg.norm(wi, axis=1, keepdims=True)
+    u = rs.uniform(0.01, 0.99, size=(n, 3)).astype(np.float32)
+    table = np.concatenate([nrm, wo, np.full((n, 2), 0.5, np.float32), wi, u], 1).astype(np.float32)
+
+    # material 0: Oren-Nayar sigma 0.6 on the 0.73 white texture
+    out = osc.bsdf_table(0, table)
+    sigma = np.float32(0.6)
+    A = np.float32(1) - sigma * sigma / (np.float32(2) * (sigma * sigma + np.float32(0.33)))
+    B = np.float32(0.45 * float(sigma) * float(sigma) / float(sigma * sigma + np.float32(0.09)))
+    # sampled direction: z = sqrt(u0), pdf = z / pi, whatever the tangent frame is
+    assert np.allclose(out[:, 6], np.sqrt(u[:, 0]) / np.pi, rtol=2e-6)
+    assert np.allclose(np.linalg.norm(out[:, 0:3], axis=1), 1, atol=1e-5)
+    assert np.allclose(out[:, 2], np.sqrt(u[:, 0]), atol=1e-6)      # normal = +z, so world z = local z
+    # evaluate: albedo/pi * (A + B max(cos(dphi),0) sin(max(ti,to) * tan(min(ti,to)))); dphi is frame independent
+    ti, to = np.arccos(wi[:, 2]), np.arccos(wo[:, 2])
+    dphi = np.arctan2(wi[:, 1], wi[:, 0]) - np.arctan2(wo[:, 1], wo[:, 0])
+    term = A + B * np.maximum(np.cos(dphi), 0) * np.sin(np.maximum(ti, to) * np.tan(np.minimum(ti, to)))
+    assert np.allclose(out[:, 7], 0.73 / np.pi * term, rtol=2e-4, atol=2e-6)
+    assert np.allclose(out[:, 10], np.abs(wi[:, 2]) / np.pi, rtol=2e-6)
+
+    # material 4: Dielectric = cosine lobe with f = albedo / pi, PDF |z| / pi (u1 drives cos theta: first draw feeds r2)
+    out = osc.bsdf_table(4, table)
+    assert np.allclose(out[:, 2], np.sqrt(u[:, 1]), atol=1e-6)
+    assert np.allclose(out[:, 6], np.sqrt(u[:, 1]) / np.pi, rtol=2e-6)
+    assert np.allclose(out[:, 3:6], 1.0 / np.pi, rtol=2e-6) and np.allclose(out[:, 7:10], 1.0 / np.pi, rtol=2e-6)
+    assert np.allclose(out[:, 10], np.abs(wi[:, 2]) / np.pi, rtol=2e-6)
+
+    # Layered(X) answers exactly like X: material 6 = Layered(Glass 1.5), material 7 = Layered(Plastic)
+    mixed = orc.scene(scenes.cornell_box("mixed"))
+    assert np.array_equal(osc.bsdf_table(6, table), mixed.bsdf_table(6, table))      # Glass 1.5 / 1.0, white
+    plastic_next, plastic_mixed = osc.bsdf_table(7, table), mixed.bsdf_table(5, table)   # same parameters, different albedo
+    assert np.array_equal(plastic_next[:, [0, 1, 2, 6, 10]], plastic_mixed[:, [0, 1, 2, 6, 10]])
+    osc.close(); mixed.close()
+
+
+def test_two_sidedness_of_the_remaining_bsdfs(pkg, lib, orc, scenes):
+    """Dielectric is one-sided (Materials.h:475), anything wrapped in LayeredBSDF two-sided
+    (:716): seen from behind, only the two-sided surface turns its normal to the viewer
+    (Scene.h:199-205)."""
+    sc = scenes.cornell_box("next")
+    osc = orc.scene(sc)
+    mi = sc.material_index
+    for mat, flips in ((4, False), (6, True)):
+        t = int(np.nonzero(mi == mat)[0][0])
+        p = sc.positions[t]; c = p.mean(0)
+        gn = np.cross(p[1] - p[0], p[2] - p[0]); gn /= np.linalg.norm(gn)
+        o = c - gn * 0.01                                             # just behind the face
+        ray = np.zeros(1, pkg.RAY_DTYPE); ray["o"] = o; ray["d"] = gn
+        hit = osc.trace_closest(ray, threads=1)
+        assert hit["id"][0] == t
+        sd = osc.shading_data(ray, hit)[0]
+        # shading_data layout: x(3) wo(3) sNormal(3) gNormal(3) ...
+        s_n = sd[6:9]
+        facing = float(np.dot(s_n, -gn))                             # wo = -d = -gn
+        assert (facing > 0) == flips, (mat, facing)
+    osc.close()
