@@ -161,6 +161,12 @@ int rtx_camera_look_at(rtx_camera* out, const float from[3], const float to[3], 
                        float fov_deg, int width, int height, int flip_x);
 int rtx_set_camera(rtx_ctx* ctx, const rtx_camera* cam);
 
+/* The vertex transform of loadInstance, RTBase/SceneLoader.h:298-316, in place on n vertices
+ * (positions and normals are n x 3 floats): p = world.mulPoint(p), normal =
+ * world.invert().transpose().mulVec(normal).normalize(). `world` is the 16 floats of the
+ * instance's "world" entry in scene.json, row-major. Host only, touches no GPU. */
+int rtx_host_transform_instance(const float world[16], size_t n, float* positions, float* normals);
+
 /* RayTracer::init's settings hand-over, RTBase/Renderer.h:69-87 (adaptive sampling is
  * gated to path tracing there; initSPP falls back to totalSPP without it). */
 int rtx_set_settings(rtx_ctx* ctx, const rtx_settings* s);

@@ -180,6 +180,13 @@ int rtx_camera_look_at(rtx_camera* out, const float from[3], const float to[3], 
     return RTX_OK;
 }
 
+int rtx_host_transform_instance(const float world[16], size_t n, float* positions, float* normals)
+{
+    if (!world || (n && (!positions || !normals))) return fail(RTX_ERR_INVALID, "null argument");
+    transform_instance(world, n, positions, normals);
+    return RTX_OK;
+}
+
 int rtx_set_camera(rtx_ctx* c, const rtx_camera* cam)
 {
     CTX_TRY(c);

@@ -57,6 +57,25 @@ inline F3 mul_vec(const float m[16], F3 v)        // Matrix::mulVec, Core.h:307
 
 } // namespace
 
+void transform_instance(const float world[16], size_t n, float* positions, float* normals)
+{
+    float inv[16], vt[16];
+    invert4(world, inv);
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) vt[r * 4 + c] = inv[c * 4 + r];     // Matrix::transpose, Core.h:253-259
+    const float* m = world;
+    for (size_t i = 0; i < n; i++) {
+        float* p = positions + 3 * i; float* q = normals + 3 * i;
+        const float x = p[0], y = p[1], z = p[2];
+        p[0] = (x * m[0] + y * m[1] + z * m[2]) + m[3];                                          // Matrix::mulPoint, Core.h:314-321
+        p[1] = (x * m[4] + y * m[5] + z * m[6]) + m[7];
+        p[2] = (x * m[8] + y * m[9] + z * m[10]) + m[11];
+        const float a = q[0], b = q[1], c = q[2];
+        const float nx = (a * vt[0] + b * vt[1] + c * vt[2]), ny = (a * vt[4] + b * vt[5] + c * vt[6]), nz = (a * vt[8] + b * vt[9] + c * vt[10]);   // mulVec, Core.h:307-313
+        const float l = 1.0f / sqrtf((nx * nx) + (ny * ny) + (nz * nz));                         // Vec3::normalize, Core.h:173-177
+        q[0] = nx * l; q[1] = ny * l; q[2] = nz * l;
+    }
+}
+
 void camera_look_at(rtx_camera& c, const float from_[3], const float to_[3], const float up_[3],
                     float fov, int width, int height, int flip_x)
 {

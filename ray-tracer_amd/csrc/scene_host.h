@@ -32,6 +32,9 @@ std::string prepare_scene(const rtx_scene_desc& d, HostScene& out);
 
 // Camera::init + Camera::updateView (RTBase/Scene.h:22-41) after loadScene's matrix set-up
 // (RTBase/SceneLoader.h:342-360).
+// loadInstance's vertex transform, RTBase/SceneLoader.h:298-316
+void transform_instance(const float world[16], size_t n, float* positions, float* normals);
+
 void camera_look_at(rtx_camera& out, const float from[3], const float to[3], const float up[3],
                     float fov_deg, int width, int height, int flip_x);
 

@@ -3,10 +3,11 @@
 // renderMT() per progressive pass with the five console statistics, save the HDR when
 // totalSPP is reached. Flags of the reference: -scene, -outputFilename, -SPP
 // (RTBase/Main.cpp:104-115); added: -alg pt|lt|ir, -bounces N, -mis 0|1, -adaptive 0|1,
-// -seed N, -png file, -dumpFilm file (raw float sums), -device N, -quiet 1.
+// -seed N, -png file, -dumpFilm file (raw float sums), -dumpScene file, -device N, -quiet 1.
 //
-// Scenes are ".rtxs" dumps (see SceneArrays.save in the Python package): the reference's own
-// GEM assets are not available offline.
+// -scene takes what the reference takes, a directory with scene.json + .gem meshes + textures
+// (GemScene.h), or an ".rtxs" dump (see SceneArrays.save in the Python package). -dumpScene file
+// writes the loaded scene as an .rtxs dump and exits without touching a GPU.
 #include <cfloat>
 #include <cmath>
 #include <fstream>
@@ -15,6 +16,7 @@
 #include <unordered_map>
 
 #include "RayTracerHost.h"
+#include "GemScene.h"
 #include "png_writer.h"
 
 SETTINGS createSettings()   // RTBase/Main.cpp:11-36, denoise off (no OIDN on this platform)
@@ -29,46 +31,47 @@ SETTINGS createSettings()   // RTBase/Main.cpp:11-36, denoise off (no OIDN on th
 }
 
 template <class T> static void rd(std::ifstream& f, T* p, size_t n) { f.read(reinterpret_cast<char*>(p), (std::streamsize)(n * sizeof(T))); if (!f) throw std::runtime_error("scene file truncated"); }
+template <class T> static void wr(std::ofstream& f, const T* p, size_t n) { f.write(reinterpret_cast<const char*>(p), (std::streamsize)(n * sizeof(T))); }
 
-struct Loaded { std::vector<Texture*> textures; Texture* env = nullptr; };
-
-// .rtxs: magic "RTXS", u32 version, camera (from, to, up, fov: 10 floats, width, height: 2 u32),
-// u32 nTex {u32 w, h, float rgb[w*h*3]}, u32 nMat {rtx_material}, u64 nTri,
-// positions, normals, uvs, material index, u32 envW, envH, env rgb, background[3]
-static Scene* loadScene(const std::string& path, int device, Loaded& keep)
+// .rtxs: magic "RTXS", u32 version (1, or 2 = a u32 flipX follows the film size), camera (from, to, up,
+// fov: 10 floats, width, height: 2 u32), u32 nTex {u32 w, h, float rgb[w*h*3]}, u32 nMat {rtx_material},
+// u64 nTri, positions, normals, uvs, material index, u32 envW, envH, env rgb, background[3]
+static void loadRtxs(const std::string& path, gem::SceneData& sd)
 {
     std::ifstream f(path, std::ios::binary);
     if (!f) throw std::runtime_error("cannot open scene " + path);
     char magic[4]; uint32_t version; rd(f, magic, 4); rd(f, &version, 1);
-    if (std::memcmp(magic, "RTXS", 4) != 0 || version != 1) throw std::runtime_error("not an .rtxs scene");
+    if (std::memcmp(magic, "RTXS", 4) != 0 || (version != 1 && version != 2)) throw std::runtime_error("not an .rtxs scene");
     float cam[10]; uint32_t wh[2]; rd(f, cam, 10); rd(f, wh, 2);
-    Scene* scene = new Scene(device);
-    scene->camera.lookAt(Vec3(cam[0], cam[1], cam[2]), Vec3(cam[3], cam[4], cam[5]), Vec3(cam[6], cam[7], cam[8]), cam[9], (int)wh[0], (int)wh[1]);
+    if (version == 2) { uint32_t fx; rd(f, &fx, 1); sd.flipX = fx ? 1 : 0; }
+    sd.from = Vec3(cam[0], cam[1], cam[2]); sd.to = Vec3(cam[3], cam[4], cam[5]); sd.up = Vec3(cam[6], cam[7], cam[8]); sd.fov = cam[9];
+    sd.width = (int)wh[0]; sd.height = (int)wh[1];
     uint32_t nTex; rd(f, &nTex, 1);
     for (uint32_t i = 0; i < nTex; i++) {
         uint32_t d[2]; rd(f, d, 2); std::vector<float> px((size_t)d[0] * d[1] * 3); rd(f, px.data(), px.size());
-        Texture* t = new Texture(); t->fromPixels((int)d[0], (int)d[1], px.data()); keep.textures.push_back(t);
+        Texture* t = new Texture(); t->fromPixels((int)d[0], (int)d[1], px.data()); sd.textures.push_back(t);
     }
     uint32_t nMat; rd(f, &nMat, 1);
-    std::vector<BSDF*> mats;
     for (uint32_t i = 0; i < nMat; i++) {
         rtx_material m; rd(f, &m, 1);
-        Texture* t = keep.textures.at((size_t)m.texture); BSDF* b = nullptr;
-        switch (m.type) {   // the factory of RTBase/SceneLoader.h:212-272
+        Texture* t = sd.textures.at((size_t)m.texture); BSDF* b = nullptr;
+        switch (m.type & ~RTX_BSDF_LAYERED) {   // the factory of RTBase/SceneLoader.h:212-272
         case RTX_BSDF_DIFFUSE: b = new DiffuseBSDF(t); break;
         case RTX_BSDF_MIRROR: b = new MirrorBSDF(t); break;
         case RTX_BSDF_CONDUCTOR: b = new ConductorBSDF(t, Colour(m.eta[0], m.eta[1], m.eta[2]), Colour(m.k[0], m.k[1], m.k[2]), m.roughness); break;
         case RTX_BSDF_GLASS: b = new GlassBSDF(t, m.int_ior, m.ext_ior); break;
         case RTX_BSDF_PLASTIC: b = new PlasticBSDF(t, m.int_ior, m.ext_ior, m.roughness); break;
+        case RTX_BSDF_DIELECTRIC: b = new DielectricBSDF(t, m.int_ior, m.ext_ior, m.roughness); break;
+        case RTX_BSDF_ORENNAYAR: b = new OrenNayarBSDF(t, m.roughness); break;
         default: throw std::runtime_error("unknown bsdf in scene");
         }
+        if (m.type & RTX_BSDF_LAYERED) b = new LayeredBSDF(b, Colour(0, 0, 0), 0.0f, 1.33f, 1.0f);
         if (m.emission[0] != 0 || m.emission[1] != 0 || m.emission[2] != 0) b->addLight(Colour(m.emission[0], m.emission[1], m.emission[2]));
-        mats.push_back(b);
+        sd.materials.push_back(b);
     }
     uint64_t nTri; rd(f, &nTri, 1);
     std::vector<float> pos(nTri * 9), nrm(nTri * 9), uv(nTri * 6); std::vector<uint32_t> mi(nTri);
     rd(f, pos.data(), pos.size()); rd(f, nrm.data(), nrm.size()); rd(f, uv.data(), uv.size()); rd(f, mi.data(), mi.size());
-    std::vector<Triangle> tris;
     for (uint64_t i = 0; i < nTri; i++) {
         Vertex v[3];
         for (int k = 0; k < 3; k++) {
@@ -77,13 +80,61 @@ static Scene* loadScene(const std::string& path, int device, Loaded& keep)
             v[k].u = uv[i * 6 + k * 2]; v[k].v = uv[i * 6 + k * 2 + 1];
         }
         Triangle t; t.init(v[0], v[1], v[2], mi[i]);
-        if (t.area > 0) tris.push_back(t);   // RTBase/SceneLoader.h:330
+        if (t.area > 0) sd.triangles.push_back(t);   // RTBase/SceneLoader.h:330
     }
     uint32_t env[2]; rd(f, env, 2);
-    Background bg;
-    if (env[0] && env[1]) { std::vector<float> px((size_t)env[0] * env[1] * 3); rd(f, px.data(), px.size()); keep.env = new Texture(); keep.env->fromPixels((int)env[0], (int)env[1], px.data()); bg.env = keep.env; }
-    float b3[3]; rd(f, b3, 3); bg.colour = Colour(b3[0], b3[1], b3[2]);
-    scene->init(tris, mats, bg);
+    if (env[0] && env[1]) { std::vector<float> px((size_t)env[0] * env[1] * 3); rd(f, px.data(), px.size()); sd.env = new Texture(); sd.env->fromPixels((int)env[0], (int)env[1], px.data()); }
+    float b3[3]; rd(f, b3, 3); sd.background = Colour(b3[0], b3[1], b3[2]);
+}
+
+// What Scene::build would upload, as an .rtxs file: lets a loaded GEM scene be inspected (and
+// re-rendered) without the scene directory, and needs no GPU.
+static void dumpRtxs(const std::string& path, const gem::SceneData& sd)
+{
+    std::ofstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot write " + path);
+    const uint32_t version = 2; f.write("RTXS", 4); wr(f, &version, 1);
+    const float cam[10] = {sd.from.x, sd.from.y, sd.from.z, sd.to.x, sd.to.y, sd.to.z, sd.up.x, sd.up.y, sd.up.z, sd.fov};
+    const uint32_t wh[2] = {(uint32_t)sd.width, (uint32_t)sd.height}, fx = (uint32_t)sd.flipX;
+    wr(f, cam, 10); wr(f, wh, 2); wr(f, &fx, 1);
+    std::vector<Texture*> texList; std::vector<rtx_material> mats;
+    for (BSDF* b : sd.materials) {
+        rtx_material m = b->describe();
+        size_t t = 0; while (t < texList.size() && texList[t] != b->albedo) t++;
+        if (t == texList.size()) texList.push_back(b->albedo);
+        m.texture = (int32_t)t; mats.push_back(m);
+    }
+    const uint32_t nTex = (uint32_t)texList.size(); wr(f, &nTex, 1);
+    for (Texture* t : texList) { const uint32_t d[2] = {(uint32_t)t->width, (uint32_t)t->height}; wr(f, d, 2); wr(f, &t->texels[0].r, t->texels.size() * 3); }
+    const uint32_t nMat = (uint32_t)mats.size(); wr(f, &nMat, 1); wr(f, mats.data(), mats.size());
+    const uint64_t nTri = sd.triangles.size(); wr(f, &nTri, 1);
+    for (int what = 0; what < 4; what++) for (const Triangle& t : sd.triangles) {
+        if (what == 3) { const uint32_t m = t.materialIndex; wr(f, &m, 1); continue; }
+        for (int k = 0; k < 3; k++) {
+            const Vertex& v = t.vertices[k];
+            if (what == 0) { const float p[3] = {v.p.x, v.p.y, v.p.z}; wr(f, p, 3); }
+            if (what == 1) { const float n[3] = {v.normal.x, v.normal.y, v.normal.z}; wr(f, n, 3); }
+            if (what == 2) { const float u[2] = {v.u, v.v}; wr(f, u, 2); }
+        }
+    }
+    const uint32_t env[2] = {sd.env ? (uint32_t)sd.env->width : 0u, sd.env ? (uint32_t)sd.env->height : 0u}; wr(f, env, 2);
+    if (sd.env) wr(f, &sd.env->texels[0].r, sd.env->texels.size() * 3);
+    const float b3[3] = {sd.background.r, sd.background.g, sd.background.b}; wr(f, b3, 3);
+}
+
+// loadScene, RTBase/SceneLoader.h:337-389: a directory with scene.json is a GEM scene, anything else an .rtxs dump
+static void loadSceneData(const std::string& path, gem::SceneData& sd)
+{
+    std::ifstream probe(path + "/scene.json");
+    if (probe) gem::loadGemScene(path, sd); else loadRtxs(path, sd);
+}
+
+static Scene* buildScene(const gem::SceneData& sd, int device)
+{
+    Scene* scene = new Scene(device);
+    scene->camera.lookAt(sd.from, sd.to, sd.up, sd.fov, sd.width, sd.height, sd.flipX);
+    Background bg; bg.colour = sd.background; bg.env = sd.env;
+    scene->init(sd.triangles, sd.materials, bg);
     scene->build();
     return scene;
 }
@@ -91,7 +142,7 @@ static Scene* loadScene(const std::string& path, int device, Loaded& keep)
 int main(int argc, char* argv[])
 {
     SETTINGS settings = createSettings();
-    std::string sceneName, filename = "render_GI.hdr", png, dump; int device = 0; bool quiet = false;
+    std::string sceneName, filename = "render_GI.hdr", png, dump, dumpScene; int device = 0; bool quiet = false;
     std::unordered_map<std::string, std::string> args;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -110,15 +161,18 @@ int main(int argc, char* argv[])
         else if (p.first == "-seed") settings.seed = (unsigned)std::stoul(p.second);
         else if (p.first == "-png") png = p.second;
         else if (p.first == "-dumpFilm") dump = p.second;
+        else if (p.first == "-dumpScene") dumpScene = p.second;
         else if (p.first == "-device") device = std::stoi(p.second);
         else if (p.first == "-quiet") quiet = std::stoi(p.second) != 0;
         else std::cerr << "Warning: unknown flag '" << p.first << "'\n";
     }
-    if (sceneName.empty()) { std::cerr << "usage: rt_headless -scene file.rtxs [-outputFilename out.hdr] [-SPP n] ...\n"; return 2; }
+    if (sceneName.empty()) { std::cerr << "usage: rt_headless -scene <scene directory | file.rtxs> [-outputFilename out.hdr] [-SPP n] ...\n"; return 2; }
     try {
-        Loaded keep;
+        gem::SceneData data;
         std::cout << "Loading scene: " << sceneName << std::endl;
-        Scene* scene = loadScene(sceneName, device, keep);
+        loadSceneData(sceneName, data);
+        if (!dumpScene.empty()) { dumpRtxs(dumpScene, data); std::cout << "Wrote " << dumpScene << " (" << data.triangles.size() << " triangles, " << data.materials.size() << " materials)" << std::endl; return 0; }
+        Scene* scene = buildScene(data, device);
         GamesEngineeringBase::Window canvas;
         canvas.create((unsigned int)scene->camera.width, (unsigned int)scene->camera.height, "Tracer", 1.0f);
         RayTracer rt;
