@@ -52,11 +52,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # RTX_BENCH_REHEARSAL=1: every rank on GPU 0 and gloo instead of RCCL, to walk the multi-rank
+    # control flow on a one-GPU box (RCCL refuses two ranks on one device)
+    rehearse = os.environ.get("RTX_BENCH_REHEARSAL") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    def all_reduce(t, op=None):
+        op = op or dist.ReduceOp.SUM
+        if rehearse:
+            c = t.cpu(); dist.all_reduce(c, op=op); t.copy_(c)
+        else:
+            dist.all_reduce(t, op=op)
 
     pkg = importlib.import_module("ray-tracer_amd")
     scenes = importlib.import_module("ray-tracer_amd.scenes")
@@ -121,7 +136,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
     mrays = world * n * args.steps / elapsed / 1e6
 
@@ -154,7 +169,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, scene, cam, args)
     if not args.no_pathtrace:
-        pt = pathtrace_side(pkg, scenes, lib, core, torch, dist, world, rank, dev, args)
+        pt = pathtrace_side(pkg, scenes, lib, core, torch, dist, world, rank, dev, args, all_reduce)
         if pt:
             out.update(pt)
     if rank == 0:
@@ -212,7 +227,7 @@ def cpu_baseline(pkg, scene, cam, args):
             "sample": f"every 2nd ray of the batch ({len(rays)} rays), {threads} threads, BVH build excluded"}
 
 
-def pathtrace_side(pkg, scenes, lib, core, torch, dist, world, rank, dev, args):
+def pathtrace_side(pkg, scenes, lib, core, torch, dist, world, rank, dev, args, all_reduce):
     """1080p path tracing of the mixed-material scene under the environment map
     (BASELINE.json configs[2]); samples are split over the ranks (shard_mode 2) and the films
     summed with one RCCL all-reduce at the end."""
@@ -237,12 +252,12 @@ def pathtrace_side(pkg, scenes, lib, core, torch, dist, world, rank, dev, args):
             film = torch.empty(nfl, dtype=torch.float32, device=dev)
             ctypes.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(ctypes.c_void_p(film.data_ptr()), ctypes.c_void_p(ptr),
                                                                    ctypes.c_size_t(nfl * 4), 3)
-            dist.all_reduce(film)
+            all_reduce(film)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            all_reduce(t, dist.ReduceOp.MAX)
             dt = float(t.item())
         s = core.stats()
         return {"pathtrace_spp_per_s": round(args.pt_spp * world / dt, 3),
