@@ -208,6 +208,14 @@ int rtx_set_spp(rtx_ctx* ctx, int spp);
 
 /* Scene::traverse, RTBase/Scene.h:137-141 → BVHTree::traverse, RTBase/Geometry.h:506-566,
  * for n rays in host memory. */
+/* RayTracer::createAOV, RTBase/Renderer.h:786-820: the three input planes of the denoiser, W*H*3
+ * floats each, any pointer may be NULL. color = film / spp (per-tile spp once adaptive sampling
+ * has taken over, :798-802); albedo = RayTracer::albedo (:553-565) and normal =
+ * RayTracer::viewNormals (:567-575) through the pixel centres. Blocking; the _device variant takes
+ * device pointers and only enqueues. */
+int rtx_create_aov(rtx_ctx* ctx, float* color, float* albedo, float* normal);
+int rtx_create_aov_device(rtx_ctx* ctx, float* color, float* albedo, float* normal);
+
 int rtx_trace_closest(rtx_ctx* ctx, const rtx_ray* rays, size_t n, rtx_hit* hits);
 /* Same, rays and hits already in device memory (no copies, asynchronous on the stream). */
 int rtx_trace_closest_device(rtx_ctx* ctx, const rtx_ray* rays_dev, size_t n, rtx_hit* hits_dev);

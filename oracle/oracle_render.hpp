@@ -708,6 +708,28 @@ struct Renderer {
         return rgb(0, 0, 0);
     }
 
+    // RayTracer::createAOV, Renderer.h:786-820: colour = film / spp (per-tile spp under adaptive
+    // sampling), albedo and view normals through the pixel centres; W*H*3 floats each
+    void createAOV(float* color, float* albedoOut, float* normalOut) const
+    {
+        for (unsigned y = 0; y < film.height; y++) {
+            int sppY = (y / tileSize) * totalXTiles;
+            for (unsigned x = 0; x < film.width; x++) {
+                unsigned index = y * film.width + x;
+                int sppIndex = sppY + x / tileSize;
+                int spp = st.adaptive_sampling && (int)st.init_spp < film.SPP ? (int)wmin(tileSamples[sppIndex], (unsigned)film.SPP) : film.SPP;
+                RGB col = film.film[index] / (float)spp;
+                color[index * 3] = col.r; color[index * 3 + 1] = col.g; color[index * 3 + 2] = col.b;
+                float px = x + 0.5f, py = y + 0.5f;
+                Ray ray = scene->camera.generateRay(px, py);
+                col = albedo(ray);
+                albedoOut[index * 3] = col.r; albedoOut[index * 3 + 1] = col.g; albedoOut[index * 3 + 2] = col.b;
+                col = viewNormals(ray);
+                normalOut[index * 3] = col.r; normalOut[index * 3 + 1] = col.g; normalOut[index * 3 + 2] = col.b;
+            }
+        }
+    }
+
     // ---- light tracing: Renderer.h:308-411 ----
     void connectToCamera(V3 p, V3 n, RGB col)                                            // Renderer.h:308-334
     {

@@ -58,6 +58,7 @@ class Oracle:
         lib.orc_film_read.argtypes = [vp, vp, C.POINTER(C.c_int), vp]
         lib.orc_film_write.argtypes = [vp, vp, C.c_int]
         lib.orc_calculate_tile_samples.argtypes = [vp]
+        lib.orc_create_aov.argtypes = [vp, vp, vp, vp]
         lib.orc_film_splat.argtypes = [vp, vp, C.c_size_t]
         lib.orc_rng.argtypes = [C.c_uint32] * 5; lib.orc_rng.restype = C.c_float
 
@@ -195,6 +196,12 @@ class OracleRenderer:
     def film_write(self, rgb, spp):
         rgb = np.ascontiguousarray(rgb, np.float32)
         self.lib.orc_film_write(self.h, _p(rgb), spp)
+
+    def create_aov(self):
+        w, h = self.s.width, self.s.height
+        c, a, n = (np.empty((h, w, 3), np.float32) for _ in range(3))
+        self.lib.orc_create_aov(self.h, _p(c), _p(a), _p(n))
+        return c, a, n
 
     def calculate_tile_samples(self):
         self.lib.orc_calculate_tile_samples(self.h)

@@ -168,6 +168,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "rtx_trace_visible": [vp, vp, sz, vp], "rtx_trace_visible_device": [vp, vp, sz, vp],
         "rtx_generate_primary_rays_device": [vp, vp, vp, sz],
         "rtx_get_bvh": [vp, C.POINTER(C.c_uint32), vp, vp, vp],
+        "rtx_create_aov": [vp, vp, vp, vp], "rtx_create_aov_device": [vp, vp, vp, vp],
         "rtx_get_stats": [vp, C.POINTER(Stats)], "rtx_reset_stats": [vp],
         "rtx_timer_begin": [vp], "rtx_timer_end": [vp, C.POINTER(C.c_float)],
         "rtx_count_closest_work": [vp, vp, sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
@@ -342,6 +343,13 @@ class Core:
         s = Stats()
         self._check(self.lib.rtx_get_stats(self.ctx, C.byref(s)))
         return s
+
+    def create_aov(self):
+        """RayTracer::createAOV, RTBase/Renderer.h:786-820: (color, albedo, normal), H x W x 3 each."""
+        w, h = self.width, self.height
+        planes = [np.empty((h, w, 3), np.float32) for _ in range(3)]
+        self._check(self.lib.rtx_create_aov(self.ctx, *(p.ctypes.data for p in planes)))
+        return tuple(planes)
 
     def reset_stats(self):
         self._check(self.lib.rtx_reset_stats(self.ctx))

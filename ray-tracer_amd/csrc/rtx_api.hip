@@ -328,6 +328,33 @@ int rtx_update_tile_samples(rtx_ctx* c)
     return RTX_OK;
 }
 
+// ---- denoiser inputs -----------------------------------------------------------------------
+
+int rtx_create_aov_device(rtx_ctx* c, float* color, float* albedo, float* normal)
+{
+    CTX_TRY(c);
+    if (!c->have_scene || !c->have_camera) return fail(RTX_ERR_STATE, "scene and camera must be set first");
+    int rc = wavefront_aov(c, color, albedo, normal);
+    if (rc) return fail(rc, "AOV pass failed");
+    return RTX_OK;
+}
+
+int rtx_create_aov(rtx_ctx* c, float* color, float* albedo, float* normal)
+{
+    CTX_TRY(c);
+    if (!c->have_scene || !c->have_camera) return fail(RTX_ERR_STATE, "scene and camera must be set first");
+    const size_t plane = (size_t)c->cam.width * c->cam.height * 3 * sizeof(float);
+    HIP_TRY(c->b_io_a.ensure(plane * 3));
+    float* d = c->b_io_a.as<float>(); const size_t n = plane / sizeof(float);
+    int rc = rtx_create_aov_device(c, color ? d : nullptr, albedo ? d + n : nullptr, normal ? d + 2 * n : nullptr);
+    if (rc) return rc;
+    if (color) HIP_TRY(hipMemcpyAsync(color, d, plane, hipMemcpyDeviceToHost, c->stream));
+    if (albedo) HIP_TRY(hipMemcpyAsync(albedo, d + n, plane, hipMemcpyDeviceToHost, c->stream));
+    if (normal) HIP_TRY(hipMemcpyAsync(normal, d + 2 * n, plane, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RTX_OK;
+}
+
 // ---- ray queries -------------------------------------------------------------------------
 
 int rtx_trace_closest_device(rtx_ctx* c, const rtx_ray* rays, size_t n, rtx_hit* hits)

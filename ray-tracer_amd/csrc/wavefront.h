@@ -642,6 +642,19 @@ __global__ __launch_bounds__(kBlock) void k_tile_samples(WfPtrs w, int spp, uint
     w.tile_samples[i] = (uint32_t)((float)spp + (float)(total_spp - (uint32_t)spp) * weight);
 }
 
+// Colour plane of RayTracer::createAOV, RTBase/Renderer.h:798-805: film / spp, with the tile's
+// own sample count once adaptive sampling has taken over
+__global__ __launch_bounds__(kBlock) void k_aov_color(WfPtrs w, float* __restrict__ color, int film_spp, int adaptive, int init_spp)
+{
+    const uint32_t i = global_thread();
+    if (i >= w.W * w.H) return;
+    const uint32_t x = i % w.W, y = i / w.W;
+    const uint32_t tile = (y / 16u) * w.tiles_x + x / 16u;
+    const int spp = (adaptive && init_spp < film_spp) ? (int)min(w.tile_samples[tile], (uint32_t)film_spp) : film_spp;
+    const C3 c = ldc(w.film + 3 * (size_t)i) / (float)spp;
+    st3(color + 3 * (size_t)i, c);
+}
+
 // ---- host side --------------------------------------------------------------------------------
 
 inline void wavefront_release(rtx_ctx* c) { for (auto& wf : c->wf) { delete wf; wf = nullptr; } }
@@ -686,6 +699,35 @@ inline int wavefront_tile_samples(rtx_ctx* c, hipStream_t stream)
     if (!c->wf[0]) return RTX_ERR_STATE;
     WfPtrs& w = c->wf[0]->p;
     hipLaunchKernelGGL(k_tile_samples, dim3((w.n_tiles + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, w, c->spp, c->settings.total_spp);
+    return hipGetLastError() == hipSuccess ? RTX_OK : RTX_ERR_HIP;
+}
+
+// RayTracer::createAOV, RTBase/Renderer.h:786-820, into device planes of W*H*3 floats (any may be
+// null): colour = film / spp; albedo and normals = the draw-mode integrators through the pixel
+// centres (:699-720 with DM_ALBEDO / DM_NORMALS), rendered into the plane instead of the film.
+inline int wavefront_aov(rtx_ctx* c, float* color, float* albedo, float* normal)
+{
+    if (!c->wf[0]) return RTX_ERR_STATE;
+    WfPtrs w = c->wf[0]->p; hipStream_t s = c->stream;
+    const dim3 blk(kBlock), gridP((w.P + kBlock - 1) / kBlock), gridQ(std::min<uint32_t>((w.P + kBlock - 1) / kBlock, kMaxGridBlocks)),
+               gridT(std::min<uint32_t>((w.P + kBlock - 1) / kBlock, (uint32_t)c->resident_blocks));
+    const size_t plane = (size_t)w.W * w.H * 3 * sizeof(float);
+    if (color) hipLaunchKernelGGL(k_aov_color, dim3((w.W * w.H + kBlock - 1) / kBlock), blk, 0, s, w, color, c->spp, (int)c->settings.adaptive_sampling, (int)c->settings.init_spp);
+    for (int which = 0; which < 2; which++) {
+        float* target = which == 0 ? albedo : normal;
+        if (!target) continue;
+        PassParams pp; pp.st = c->settings; pp.spp = 1; pp.sample_index = 1; pp.depth = 0;
+        pp.st.draw_mode = which == 0 ? RTX_DM_ALBEDO : RTX_DM_NORMALS;
+        pp.st.algorithm = RTX_AL_PATH_TRACE; pp.st.filter = RTX_FT_BOX; pp.st.init_spp = 0x7FFFFFFF; pp.st.shard_mode = 0; pp.st.shard_world = 1;   // every tile, whole film
+        w.film = target;
+        if (hipMemsetAsync(target, 0, plane, s) != hipSuccess || hipMemsetAsync(w.cnt, 0, kCounterWords * 4, s) != hipSuccess) return RTX_ERR_HIP;
+        hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, w, pp);
+        hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
+        hipLaunchKernelGGL(k_closest<false>, gridT, blk, 0, s, c->dscene, (const rtx_ray*)w.ray, (const uint32_t*)w.qa, 0u, (const uint32_t*)w.cnt, w.hit,
+                           c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), w.cnt + kClosestWorkBase, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL(k_dm_shade, gridQ, blk, 0, s, w, c->dscene, pp);
+        hipLaunchKernelGGL(k_film_accumulate, gridP, blk, 0, s, w, (int)RTX_FT_BOX);
+    }
     return hipGetLastError() == hipSuccess ? RTX_OK : RTX_ERR_HIP;
 }
 

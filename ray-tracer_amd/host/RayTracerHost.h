@@ -273,7 +273,12 @@ public:
     void tonemap(int x, int y, unsigned char& r, unsigned char& g, unsigned char& b, int spp, TONEMAP tm = TM_LINEAR) const
     {
         Colour p = film[(size_t)y * width + x] / (float)spp;
-        float c[3] = {std::fmax(p.r, 0.0f), std::fmax(p.g, 0.0f), std::fmax(p.b, 0.0f)};
+        tonemap(p.r, p.g, p.b, r, g, b, tm);
+    }
+    // tonemap(r, g, b, ...), Imaging.h:236-316: an already normalised colour
+    void tonemap(float pr, float pg, float pb, unsigned char& r, unsigned char& g, unsigned char& b, TONEMAP tm = TM_LINEAR) const
+    {
+        float c[3] = {std::fmax(pr, 0.0f), std::fmax(pg, 0.0f), std::fmax(pb, 0.0f)};
         const float inv2p2 = 1.0f / 2.2f;
         for (float& v : c) {
             switch (tm) {
@@ -305,6 +310,14 @@ public:
         }
         fclose(f);
     }
+};
+
+// The denoiser's input / output planes, RTBase/Denoiser.h:14-36
+struct AOV {
+    std::vector<float> albedo, normal, color, output; unsigned int width = 0, height = 0;
+    AOV() = default;
+    AOV(unsigned int w, unsigned int h) : width(w), height(h)
+    { albedo.resize((size_t)w * h * 3, 0); normal.resize((size_t)w * h * 3, 0); color.resize((size_t)w * h * 3, 0); output.resize((size_t)w * h * 3, 0); }
 };
 
 class RayTracer {                                                           // Renderer.h:25-870
@@ -347,6 +360,20 @@ public:
             int spp = settings.adaptiveSampling && (int)settings.initSPP < film->SPP ? (int)std::min<unsigned>(tileSamples[idx], (unsigned)film->SPP) : film->SPP;
             film->tonemap((int)x, (int)y, r, g, b, spp, settings.toneMap);
             canvas->draw((int)(y * film->width + x), r, g, b);
+        }
+    }
+    // Renderer.h:786-820: colour, albedo and normal planes for a denoiser (output is left for it to fill)
+    void createAOV(AOV& aov)
+    {
+        aov = AOV(film->width, film->height);
+        rtxCheck(rtx_create_aov(scene->ctx, aov.color.data(), aov.albedo.data(), aov.normal.data()), "RayTracer::createAOV");
+    }
+    void draw(const AOV& aov)                                                                  // Renderer.h:839-854
+    {
+        unsigned char r, g, b;
+        for (size_t i = 0; i < (size_t)film->width * film->height; i++) {
+            film->tonemap(aov.output[i * 3], aov.output[i * 3 + 1], aov.output[i * 3 + 2], r, g, b, settings.toneMap);
+            canvas->draw((int)i, r, g, b);
         }
     }
     void saveHDR(const std::string& filename) { fetch(); film->save(filename); }              // Renderer.h:861

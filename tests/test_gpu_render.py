@@ -193,3 +193,29 @@ def test_converged_radiance_vs_reference_streams(pkg, lib, core, orc, scenes):
     floor = rmse(imgs[0], imgs[1])
     assert rmse(imgs[0], o) <= 1.5 * floor + 0.005 * o.mean(), (rmse(imgs[0], o), floor, o.mean())
     assert abs(imgs[0].mean() - o.mean()) <= 0.015 * o.mean()
+
+
+def test_create_aov_planes(pkg, lib, core, orc, scenes):
+    """RayTracer::createAOV (Renderer.h:786-820): colour = film / spp with per-tile spp under
+    adaptive sampling, albedo and normals through the pixel centres."""
+    st, osc = _setup(pkg, lib, core, orc, scenes.cornell_box("mixed"), scenes.cornell_camera(), 100, 70,
+                     total_spp=12, init_spp=3, adaptive_sampling=1, seed=4)
+    r = osc.renderer(st, threads=4, counter_rng=True)
+    core.render_passes(3)                         # = initSPP: the tile targets are computed from this film
+    film3, spp3, _ = core.film()
+    r.film_write(film3, spp3)
+    r.calculate_tile_samples()
+    core.render_passes(3)                         # tiles past their target are skipped now
+    film, spp, tiles = core.film()
+    color, albedo, normal = core.create_aov()
+    r.film_write(film, spp)                       # same accumulated film on the oracle's side
+    _, _, otiles = r.film()
+    assert np.array_equal(otiles, tiles) and tiles.min() < spp
+    oc, oa, on = r.create_aov()
+    assert np.array_equal(color, oc)
+    assert (albedo > 0).any() and (normal > 0).any()
+    _assert_films_match(albedo, oa, "albedo plane", frac=0.002)
+    _assert_films_match(normal, on, "normal plane", frac=0.002)
+    # the film itself is untouched by the AOV passes
+    film2, spp2, _ = core.film()
+    assert spp2 == spp and np.array_equal(film2, film)
