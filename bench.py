@@ -240,9 +240,11 @@ def pathtrace_side(pkg, scenes, lib, core, torch, dist, world, rank, dev, args, 
                                shard_rank=rank, shard_world=world)
         core.set_settings(st)
         core.clear()
-        core.render_passes(2)          # warm-up
+        core.render_passes(4)          # warm-up (also brings up every pipeline lane's buffers)
         core.clear()
         if world > 1:
+            ptr, nfl = core.film_device()
+            all_reduce(torch.zeros(nfl, dtype=torch.float32, device=dev))     # warm-up of the collective at film size
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
