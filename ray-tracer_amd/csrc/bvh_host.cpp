@@ -4,7 +4,9 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstring>
+#include <cstdlib>
 #include <deque>
+#include <thread>
 
 namespace rtx {
 
@@ -49,9 +51,13 @@ inline float nodeArea(const Bvh2Node& n)
     return ((sx * sy) + (sy * sz) + (sx * sz)) * 2.0f;
 }
 
+// Builds into a node vector of its own (the subtree's root at index 0) over a range of the
+// shared index array; subtrees own disjoint index ranges, so they can be built concurrently.
+struct SubTree { std::vector<Bvh2Node> nodes; std::vector<uint32_t>& indices; };
+
 struct Builder {
     const TriPrep* tris;
-    Bvh2& out;
+    SubTree& out;
     const float invBins = 1.0f / (float)kBins;   // Geometry.h:307
 
     // splitNode + createSplit, Geometry.h:345-430. The reference evaluates each of the
@@ -151,18 +157,52 @@ void prepare_triangles(const float* p, uint64_t n, std::vector<TriPrep>& out, fl
     }
 }
 
+namespace {
+
+// The reference numbers nodes in the order split() creates them (Geometry.h:381-386, 444-445):
+// a node's two children side by side, then everything below the left child, then everything
+// below the right child. A subtree built on its own therefore only needs its ids shifted.
+uint32_t build_subtree(const TriPrep* tris, SubTree& st, int depth, int threads)
+{
+    Builder b{tris, st};
+    const uint32_t count = st.nodes[0].end - st.nodes[0].start;
+    if (threads <= 1 || count < 50000u) return b.split(0, depth);
+    if (depth >= kMaxDepth) return (uint32_t)depth;
+    if (!b.splitNode(0)) return (uint32_t)depth;
+    depth++;
+    SubTree left{{st.nodes[1]}, st.indices}, right{{st.nodes[2]}, st.indices};
+    uint32_t dl = 0, dr = 0;
+    const int tl = threads / 2, tr = threads - tl;
+    std::thread worker([&]() { dl = build_subtree(tris, left, depth, tl); });
+    dr = build_subtree(tris, right, depth, tr);
+    worker.join();
+    auto place = [&](const std::vector<Bvh2Node>& sub, uint32_t self, uint32_t shift) {
+        auto moved = [&](Bvh2Node n) { if (n.child_l != 0 || n.child_r != 0) { n.child_l += shift; n.child_r += shift; } return n; };
+        st.nodes[self] = moved(sub[0]);
+        for (size_t j = 1; j < sub.size(); j++) st.nodes.push_back(moved(sub[j]));
+    };
+    st.nodes.reserve(3 + left.nodes.size() + right.nodes.size());
+    place(left.nodes, 1, 2);                                   // local id j >= 1 of the left block lands at 3 + (j - 1)
+    place(right.nodes, 2, (uint32_t)left.nodes.size() + 1);    // ... of the right block behind the left block
+    return std::max(dl, dr);
+}
+
+} // namespace
+
 void build_bvh2(const std::vector<TriPrep>& tris, const float smin[3], const float smax[3], Bvh2& out)
 {
     out.nodes.clear();
     out.indices.resize(tris.size());
     for (uint32_t i = 0; i < tris.size(); i++) out.indices[i] = i;
-    out.nodes.reserve(tris.size() / 2 + 16);
     Bvh2Node root{};
     for (int a = 0; a < 3; a++) { root.bmin[a] = smin[a]; root.bmax[a] = smax[a]; }
     root.start = 0; root.end = (uint32_t)tris.size();
-    out.nodes.push_back(root);
-    Builder b{tris.data(), out};
-    out.depth = tris.empty() ? 0 : b.split(0, 0);
+    int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("RTX_BUILD_THREADS")) threads = std::max(1, atoi(e));
+    SubTree st{{root}, out.indices};
+    st.nodes.reserve(tris.size() / 2 + 16);
+    out.depth = tris.empty() ? 0 : build_subtree(tris.data(), st, 0, threads);
+    out.nodes = std::move(st.nodes);
 }
 
 void flatten_bvh4(const Bvh2& in, Bvh4& out)
