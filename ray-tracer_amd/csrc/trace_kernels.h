@@ -48,8 +48,8 @@ __device__ __forceinline__ rtx_hit make_hit(const DeviceScene& sc, const HitRec&
 __global__ __launch_bounds__(kBlock) void k_closest_static(DeviceScene sc, const rtx_ray* __restrict__ rays, uint32_t n, rtx_hit* __restrict__ hits,
                                                            uint2* spill, uint32_t spill_stride)
 {
-    __shared__ uint2 lds[kBlock * kLdsStack];
-    LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
+    __shared__ unsigned long long lds[kBlock * kLdsStack];
+    LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     for (uint32_t i = global_thread(); i < n; i += gridDim.x * kBlock) {
         const rtx_ray r = rays[i];
         HitRec best;
@@ -76,8 +76,8 @@ __global__ __launch_bounds__(kBlock) void k_closest(DeviceScene sc, const rtx_ra
                                                     uint32_t n_host, const uint32_t* __restrict__ n_dev, rtx_hit* __restrict__ hits,
                                                     uint2* spill, uint32_t spill_stride, uint32_t* work_counter, unsigned long long* counters)
 {
-    __shared__ uint2 lds[kBlock * kLdsStack];
-    LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
+    __shared__ unsigned long long lds[kBlock * kLdsStack];
+    LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     ClosestPolicy pol{sc, rays, queue, hits};
     traverse_dyn<ClosestPolicy, false, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes>(sc, stk, n_dev ? *n_dev : n_host, work_counter, pol, counters);
 }
@@ -87,8 +87,8 @@ template <int REFILL, int UNROLL, int SCHED, int LDS_N>
 __global__ __launch_bounds__(kBlock) void k_closest_ab(DeviceScene sc, const rtx_ray* __restrict__ rays, uint32_t n, rtx_hit* __restrict__ hits,
                                                        uint2* spill, uint32_t spill_stride, uint32_t* work_counter)
 {
-    __shared__ uint2 lds[kBlock * LDS_N];
-    LaneStack<kBlock, LDS_N> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
+    __shared__ unsigned long long lds[kBlock * LDS_N];
+    LaneStack<kBlock, LDS_N> stk; stk.init(lds, spill, spill_stride);
     ClosestPolicy pol{sc, rays, nullptr, hits};
     traverse_dyn<ClosestPolicy, false, false, REFILL, kBlock, LDS_N, UNROLL, SCHED>(sc, stk, n, work_counter, pol, nullptr);
 }
@@ -104,8 +104,8 @@ struct VisiblePolicy {
 __global__ __launch_bounds__(kBlock) void k_visible(DeviceScene sc, const float* __restrict__ p1p2, uint32_t n, uint8_t* __restrict__ visible,
                                                     uint2* spill, uint32_t spill_stride, uint32_t* work_counter)
 {
-    __shared__ uint2 lds[kBlock * kLdsStack];
-    LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
+    __shared__ unsigned long long lds[kBlock * kLdsStack];
+    LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     VisiblePolicy pol{p1p2, visible};
     traverse_dyn<VisiblePolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes>(sc, stk, n, work_counter, pol, nullptr);
 }

@@ -89,17 +89,29 @@ __device__ __forceinline__ void consider(HitRec& best, float t, float u, float v
 }
 
 // Traversal stack: the first LDS_N entries of each lane live in LDS (entry i of lane l at
-// lds[i*BLOCK + l], 8 bytes: child reference + entry distance), deeper entries in a
-// per-lane slab of global memory.
+// lds[i*BLOCK + l], 8 bytes: child reference in the low word, entry distance in the high
+// word), deeper entries in a per-lane slab of global memory. The two parts are addressed
+// through pointers that carry their address space: with plain pointers the compiler merges
+// the two stores of push() (and the two loads of pop()) into one FLAT access on a selected
+// pointer, which is slower than ds_write / global_store and waits on both memory counters.
+typedef __attribute__((address_space(3))) unsigned long long LdsWord64;
+typedef __attribute__((address_space(1))) unsigned long long GlobalWord64;
+
 template <int BLOCK, int LDS_N>
 struct LaneStack {
-    uint2* lds;        // this block's LDS array, BLOCK*LDS_N entries
-    uint2* spill;      // this lane's first global entry; consecutive entries are `stride` apart
+    LdsWord64* lds;        // this block's LDS array, BLOCK*LDS_N entries
+    GlobalWord64* spill;   // this lane's first global entry; consecutive entries are `stride` apart
     uint32_t stride;
     int sp;
+    __device__ __forceinline__ void init(unsigned long long* lds_array, uint2* spill_slab, uint32_t spill_stride)
+    {
+        lds = (LdsWord64*)lds_array;
+        spill = (GlobalWord64*)(spill_slab + blockIdx.x * (uint32_t)BLOCK + threadIdx.x);
+        stride = spill_stride; sp = 0;
+    }
     __device__ __forceinline__ void push(uint32_t ref, float tentry)
     {
-        uint2 e = make_uint2(ref, __float_as_uint(tentry));
+        const unsigned long long e = ((unsigned long long)__float_as_uint(tentry) << 32) | ref;
         if (sp < LDS_N) lds[sp * BLOCK + threadIdx.x] = e;
         else spill[(size_t)(sp - LDS_N) * stride] = e;
         sp++;
@@ -107,8 +119,10 @@ struct LaneStack {
     __device__ __forceinline__ uint2 pop()
     {
         sp--;
-        if (sp < LDS_N) return lds[sp * BLOCK + threadIdx.x];
-        return spill[(size_t)(sp - LDS_N) * stride];
+        unsigned long long e;
+        if (sp < LDS_N) e = lds[sp * BLOCK + threadIdx.x];
+        else e = spill[(size_t)(sp - LDS_N) * stride];
+        return make_uint2((uint32_t)e, (uint32_t)(e >> 32));
     }
 };
 
@@ -254,6 +268,10 @@ __device__ __forceinline__ uint32_t step_inner(const DeviceScene& sc, LaneStack<
     const uint32_t ref[4] = {__float_as_uint(cf.x), __float_as_uint(cf.y), __float_as_uint(cf.z), __float_as_uint(cf.w)};
     const float lx[4] = {lox.x, lox.y, lox.z, lox.w}, ly[4] = {loy.x, loy.y, loy.z, loy.w}, lz[4] = {loz.x, loz.y, loz.z, loz.w};
     const float hx[4] = {hix.x, hix.y, hix.z, hix.w}, hy[4] = {hiy.x, hiy.y, hiy.z, hiy.w}, hz[4] = {hiz.x, hiz.y, hiz.z, hiz.w};
+    // all four child references are needed whatever the boxes say: tested up front (and combined
+    // without short-circuit below) so that their load stays with the other six instead of becoming
+    // a dependent load behind the first box test
+    const bool valid[4] = {ref[0] != kEmptySlot, ref[1] != kEmptySlot, ref[2] != kEmptySlot, ref[3] != kEmptySlot};
     float key[4]; uint32_t kref[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -262,7 +280,7 @@ __device__ __forceinline__ uint32_t step_inner(const DeviceScene& sc, LaneStack<
         float t0z = (lz[c] - oz) * iz, t1z = (hz[c] - oz) * iz;
         float tentry = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
         float texit = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-        bool hit = !(tentry > texit || texit < 0) && (ref[c] != kEmptySlot) && !(tentry > bound);
+        const bool hit = valid[c] & !(tentry > texit || texit < 0) & !(tentry > bound);
         key[c] = hit ? tentry : FLT_MAX;
         kref[c] = hit ? ref[c] : kEmptySlot;
     }

@@ -323,8 +323,8 @@ struct ShadowAccumulatePolicy {
 };
 __global__ __launch_bounds__(kBlock) void k_shadow_accumulate(WfPtrs w, DeviceScene sc, uint32_t counter_index, uint32_t work_index, uint2* spill, uint32_t spill_stride)
 {
-    __shared__ uint2 lds[kBlock * kLdsStack];
-    LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
+    __shared__ unsigned long long lds[kBlock * kLdsStack];
+    LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     ShadowAccumulatePolicy pol{w};
     traverse_dyn<ShadowAccumulatePolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, nullptr);
 }
@@ -502,8 +502,8 @@ struct SplatPolicy {
 };
 __global__ __launch_bounds__(kBlock) void k_lt_splat(WfPtrs w, DeviceScene sc, uint32_t counter_index, uint32_t work_index, int filter, uint2* spill, uint32_t spill_stride)
 {
-    __shared__ uint2 lds[kBlock * kLdsStack];
-    LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
+    __shared__ unsigned long long lds[kBlock * kLdsStack];
+    LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     SplatPolicy pol{w, filter};
     traverse_dyn<SplatPolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, nullptr);
 }
@@ -591,8 +591,8 @@ __global__ void k_vpl_count(WfPtrs w)
 // pixel gathers from every VPL, in list order
 __global__ __launch_bounds__(kBlock) void k_ir_gather(WfPtrs w, DeviceScene sc, PassParams pp, uint2* spill, uint32_t spill_stride)
 {
-    __shared__ uint2 lds[kBlock * kLdsStack];
-    LaneStack<kBlock, kLdsStack> stk; stk.lds = lds; stk.spill = spill + global_thread(); stk.stride = spill_stride; stk.sp = 0;
+    __shared__ unsigned long long lds[kBlock * kLdsStack];
+    LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     const uint32_t n = w.cnt[0];
     const uint32_t total = *w.vpl_total;
     for (uint32_t i = global_thread(); i < n; i += gridDim.x * kBlock) {
