@@ -9,6 +9,7 @@
 
 #include "context.h"
 #include "trace_kernels.h"
+#include "bvh_device.h"
 #include "wavefront.h"
 
 using namespace rtx;
@@ -130,7 +131,14 @@ int rtx_upload_scene(rtx_ctx* c, const rtx_scene_desc* d)
     if (!d) return fail(RTX_ERR_INVALID, "scene is null");
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_scene = false;
-    std::string err = prepare_scene(*d, c->host);
+    // the BVH is built on the device unless RTX_BVH_BUILD=host asks for the host build (same tree)
+    const char* where = getenv("RTX_BVH_BUILD");
+    Bvh2BuildFn device_build = [c](const std::vector<TriPrep>& t, const float* mn, const float* mx, Bvh2& out) {
+        hipError_t e = build_bvh2_device(t, mn, mx, out, c->stream);
+        if (e != hipSuccess) fail(RTX_ERR_HIP, "device BVH build: %s", hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    std::string err = prepare_scene(*d, c->host, (where && std::string(where) == "host") ? Bvh2BuildFn() : device_build);
     if (!err.empty()) return fail(RTX_ERR_INVALID, "scene rejected: %s", err.c_str());
     const HostScene& h = c->host;
     hipStream_t s = c->stream;

@@ -3,6 +3,8 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace rtx {
@@ -109,7 +111,7 @@ void camera_look_at(rtx_camera& c, const float from_[3], const float to_[3], con
     c.view_dir[0] = vd.x; c.view_dir[1] = vd.y; c.view_dir[2] = vd.z;
 }
 
-std::string prepare_scene(const rtx_scene_desc& d, HostScene& hs)
+std::string prepare_scene(const rtx_scene_desc& d, HostScene& hs, const Bvh2BuildFn& build)
 {
     if (d.n_triangles >= kMaxTriangles) return "too many triangles (limit 2^27 - 1)";
     if (d.n_triangles && (!d.positions || !d.normals || !d.uvs || !d.material_index)) return "triangle arrays missing";
@@ -178,8 +180,16 @@ std::string prepare_scene(const rtx_scene_desc& d, HostScene& hs)
         s.material = d.material_index[i];
     }
 
-    build_bvh2(prep, smin, smax, hs.bvh2);
+    auto t1 = std::chrono::steady_clock::now();
+    if (build) { if (!build(prep, smin, smax, hs.bvh2)) return "device BVH build failed"; }
+    else build_bvh2(prep, smin, smax, hs.bvh2);
+    auto t2 = std::chrono::steady_clock::now();
     flatten_bvh4(hs.bvh2, hs.bvh4);
+    auto t3 = std::chrono::steady_clock::now();
+    if (getenv("RTX_DEBUG_COUNTERS"))
+        fprintf(stderr, "[rtx] scene preparation: triangles %.1f ms, binary BVH (%s) %.1f ms, 4-wide layout %.1f ms\n",
+                std::chrono::duration<float, std::milli>(t1 - t0).count(), build ? "device" : "host",
+                std::chrono::duration<float, std::milli>(t2 - t1).count(), std::chrono::duration<float, std::milli>(t3 - t2).count());
     hs.tris.resize(d.n_triangles);
     for (uint64_t p = 0; p < d.n_triangles; p++) {
         const uint32_t id = hs.bvh4.order[p]; const TriPrep& t = prep[id]; TriIsect& o = hs.tris[p];

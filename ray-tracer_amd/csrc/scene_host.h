@@ -2,6 +2,7 @@
 // Scene::build, the material constructors and TabulatedDistribution::init compute once).
 #pragma once
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -28,7 +29,9 @@ struct HostScene {
 };
 
 // Returns an empty string on success, otherwise the reason the description was rejected.
-std::string prepare_scene(const rtx_scene_desc& d, HostScene& out);
+// `build` replaces build_bvh2() when given (the device build); it returns false on failure.
+using Bvh2BuildFn = std::function<bool(const std::vector<TriPrep>&, const float*, const float*, Bvh2&)>;
+std::string prepare_scene(const rtx_scene_desc& d, HostScene& out, const Bvh2BuildFn& build = nullptr);
 
 // Camera::init + Camera::updateView (RTBase/Scene.h:22-41) after loadScene's matrix set-up
 // (RTBase/SceneLoader.h:342-360).

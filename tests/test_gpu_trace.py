@@ -149,3 +149,31 @@ def test_full_size_1m_soup_1080p_bit_exact(pkg, lib, core, orc, scenes):
     _assert_hits_equal(got, want)
     assert (want["id"] != 0xFFFFFFFF).sum() > 500_000
     osc.close()
+
+
+@pytest.mark.parametrize("which", ["soup", "cornell", "mixed", "ties", "terrain"])
+def test_device_bvh_build_equals_host_build(pkg, lib, core, scenes, which):
+    """The level-by-level GPU build (binning with atomics, createSplit's swap order through
+    pointer jumping) must give the tree of the host build: same numbering, bounds, index order."""
+    if which == "soup":
+        sc = scenes.soup(300_000, seed=3)
+    elif which == "cornell":
+        sc = scenes.cornell_box("mixed")
+    elif which == "mixed":
+        sc = scenes.mixed_scene(48, env_size=(32, 16))
+    elif which == "terrain":
+        sc = scenes.terrain(300)
+    else:
+        base = scenes.soup(200, seed=5, size=0.2)
+        extra = scenes.soup(3000, seed=6, size=0.05)
+        P = np.concatenate([np.tile(base.positions[:6], (40, 1, 1)), extra.positions])
+        N = np.concatenate([np.tile(base.normals[:6], (40, 1, 1)), extra.normals])
+        U = np.concatenate([np.tile(base.uvs[:6], (40, 1, 1)), extra.uvs])
+        sc = pkg.SceneArrays(P, N, U, np.zeros(len(P), np.uint32), base.materials, base.textures)
+    core.upload_scene(sc)                     # device build (the default)
+    b, t, i, d = core.bvh()
+    hb, ht, hi, hd = pkg.host_bvh(lib, sc)[:4]
+    assert d == hd
+    assert np.array_equal(t, ht), "topology / ranges differ"
+    assert np.array_equal(i, hi), "index permutation differs"
+    assert np.array_equal(b, hb), "bounds differ"
