@@ -380,9 +380,9 @@ int rtx_trace_closest_device(rtx_ctx* c, const rtx_ray* rays, size_t n, rtx_hit*
         uint32_t* wc = c->b_counters.as<uint32_t>() + kWorkSlotWords;
         HIP_TRY(hipMemsetAsync(wc, 0, kWorkSlotWords * 4, c->stream));
         const uint32_t gb = (uint32_t)dyn_grid_for(c, n);
-#define RTX_AB(V, R, U, S, L) if (c->variant == V) hipLaunchKernelGGL((k_closest_ab<R, U, S, L>), dim3(gb), dim3(kBlock), 0, c->stream, c->dscene, rays, \
+#define RTX_AB(V, R, U, S, L, W) if (c->variant == V) hipLaunchKernelGGL((k_closest_ab<R, U, S, L, W>), dim3(gb), dim3(kBlock), 0, c->stream, c->dscene, rays, \
                            (uint32_t)n, hits, c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), wc);
-        RTX_AB(2, 32, 4, 32, 12) RTX_AB(3, 16, 4, 32, 12) RTX_AB(4, 16, 2, 24, 12) RTX_AB(5, 16, 4, 0, 12)
+        RTX_AB(2, 32, 4, 32, 12, 4) RTX_AB(3, 16, 2, 24, 12, 6)   // occupancy above 4 waves/SIMD costs spills or the 4-wide leaf loads: slower
 #undef RTX_AB
     } else {
         uint32_t* wc = c->b_counters.as<uint32_t>() + kWorkSlotWords;

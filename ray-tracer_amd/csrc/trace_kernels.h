@@ -83,8 +83,8 @@ __global__ __launch_bounds__(kBlock) void k_closest(DeviceScene sc, const rtx_ra
 }
 
 // Schedules under test (A/B harness only)
-template <int REFILL, int UNROLL, int SCHED, int LDS_N>
-__global__ __launch_bounds__(kBlock) void k_closest_ab(DeviceScene sc, const rtx_ray* __restrict__ rays, uint32_t n, rtx_hit* __restrict__ hits,
+template <int REFILL, int UNROLL, int SCHED, int LDS_N, int WAVES>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_closest_ab(DeviceScene sc, const rtx_ray* __restrict__ rays, uint32_t n, rtx_hit* __restrict__ hits,
                                                        uint2* spill, uint32_t spill_stride, uint32_t* work_counter)
 {
     __shared__ unsigned long long lds[kBlock * LDS_N];
