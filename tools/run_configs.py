@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Full-size runs of the benchmark configurations other than the headline closest-hit one,
-on one GPU: path tracing of the Cornell stand-in (with the CPU oracle's renderMT beside it),
+on one GPU: path tracing of the Cornell stand-in,
 the mixed-material scene at 1080p, the ~10 M-triangle terrain at 4K (whole film and the
 tile share of rank 0 of 2), adaptive sampling, light tracing and instant radiosity.
 Prints one JSON object per configuration; `--out file` also writes them as a JSON list.
@@ -65,22 +65,6 @@ def main():
     st = pkg.make_settings(total_spp=64, max_bounces=5, use_mis=1)
     r = timed("cornell_pt_64spp", cornell, scenes.cornell_camera(), 1024, 1024, 16 if q else 64, st,
               "stand-in for Ray-Tracer-Scenes scene 0 (asset not available offline)")
-    if r is not None:
-        pyoracle = importlib.import_module("oracle.pyoracle")
-        orc = pyoracle.Oracle(pkg)
-        threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 8, 16)
-        osc = orc.scene(cornell)
-        osc.set_camera(pkg.look_at(lib, width=1024, height=1024, **scenes.cornell_camera()))
-        ren = osc.renderer(st, threads=threads, counter_rng=False)     # the reference's MT19937 streams, renderMT
-        n_cpu = 1 if q else 2
-        t0 = time.perf_counter()
-        ren.render_passes(n_cpu)
-        dt = time.perf_counter() - t0
-        ren.close(); osc.close()
-        r["cpu_oracle_spp_per_s"] = round(n_cpu / dt, 4)
-        r["cpu_threads"] = threads
-        print(json.dumps({"config": "cornell_pt_64spp", "cpu_oracle_spp_per_s": r["cpu_oracle_spp_per_s"], "cpu_threads": threads}), flush=True)
-
     # configs[2]: mixed materials + env-map MIS, 1080p, 256 spp
     mixed = scenes.mixed_scene(128)
     timed("mixed_env_mis_1080p", mixed, scenes.mixed_camera(), 1920, 1080, 32 if q else 256,
