@@ -238,11 +238,7 @@ __device__ __forceinline__ bool traverse(const DeviceScene& sc, LaneStack<BLOCK,
 }
 
 
-// ---- phase-batched traversal ("while-while") ------------------------------------------------
-// Same candidates, same result as traverse(); only the schedule differs: every lane keeps
-// descending inner nodes until it holds a leaf (or has finished), then the wave tests leaf
-// triangles together. On a 64-wide wave this keeps far more lanes busy than alternating
-// one node step and one leaf step per iteration.
+// ---- building blocks of the dynamic schedule (traverse_dyn.h) ---------------------------------
 constexpr uint32_t kDone = kEmptySlot;
 
 template <int BLOCK, int LDS_N>
@@ -293,40 +289,6 @@ __device__ __forceinline__ uint32_t step_inner(const DeviceScene& sc, LaneStack<
     if (kref[1] != kEmptySlot) stk.push(kref[1], key[1]);
     if (kref[0] != kEmptySlot) return kref[0];
     return pop_next(stk, bound);
-}
-
-template <bool ANY, bool COUNT, int BLOCK, int LDS_N>
-__device__ __forceinline__ bool traverse_batched(const DeviceScene& sc, LaneStack<BLOCK, LDS_N>& stk,
-                                                 float ox, float oy, float oz, float dx, float dy, float dz,
-                                                 float maxT, HitRec& best, TravCount* cnt)
-{
-    best.t = FLT_MAX; best.u = 0; best.v = 0; best.pos = 0xFFFFFFFFu;
-    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
-    if (!slab_reference(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2],
-                        ox, oy, oz, ix, iy, iz))
-        return false;
-    const bool finite = (fabsf(ix) <= FLT_MAX) && (fabsf(iy) <= FLT_MAX) && (fabsf(iz) <= FLT_MAX);
-    if (!finite) { traverse_exact<ANY, BLOCK, LDS_N>(sc, stk, ox, oy, oz, dx, dy, dz, ix, iy, iz, maxT, best); return true; }
-    stk.sp = 0;
-    uint32_t cur = 0;
-    float bound = ANY ? (maxT + (fabsf(maxT) * kCullRel + kCullAbs)) : FLT_MAX;
-    for (;;) {
-        while (!(cur & kLeafBit) && cur != kDone) cur = step_inner<COUNT>(sc, stk, cur, ox, oy, oz, ix, iy, iz, bound, cnt);
-        if (cur == kDone) break;
-        const uint32_t first = cur & 0x07FFFFFFu, n = ((cur >> 27) & 15u) + 1u;
-        for (uint32_t k = 0; k < n; k++) {
-            TriIsect T = sc.tris[first + k];
-            if (COUNT) cnt->tris++;
-            float t, u, v;
-            if (tri_test(T, ox, oy, oz, dx, dy, dz, t, u, v)) {
-                if (ANY) { if (t <= maxT) { best.pos = first + k; best.t = t; return true; } }
-                else consider(best, t, u, v, first + k);
-            }
-        }
-        if (!ANY) bound = best.t + (fabsf(best.t) * kCullRel + kCullAbs);
-        cur = pop_next(stk, bound);
-    }
-    return true;
 }
 
 } // namespace rtx
