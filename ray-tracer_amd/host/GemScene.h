@@ -29,6 +29,7 @@
 #include <zlib.h>
 
 #include <cctype>
+#include <cfloat>
 #include <fstream>
 #include <iostream>
 #include <map>
@@ -375,3 +376,25 @@ inline void loadGemScene(const std::string& dir, SceneData& sd)
 }
 
 } // namespace gem
+
+// loadScene, RTBase/SceneLoader.h:337-389, with the reference's signature (plus the device to
+// render on): reads the scene directory, sets up the camera and the viewer's fly-through
+// camera, builds the scene on the device. The caller deletes the scene (RTBase/Main.cpp:226).
+inline Scene* loadScene(std::string sceneName, RTCamera& viewcamera, int device = 0, gem::SceneData* keep = nullptr)
+{
+    gem::SceneData* sd = keep ? keep : new gem::SceneData();      // textures and BSDFs live as long as the scene (the reference leaks them too)
+    gem::loadGemScene(sceneName, *sd);
+    Scene* scene = new Scene(device);
+    scene->camera.lookAt(sd->from, sd->to, sd->up, sd->fov, sd->width, sd->height, sd->flipX);
+    viewcamera.from = sd->from; viewcamera.to = sd->to; viewcamera.up = sd->up; viewcamera.camera = &scene->camera;
+    Background bg; bg.colour = sd->background; bg.env = sd->env;
+    scene->init(sd->triangles, sd->materials, bg);
+    Vec3 mn(FLT_MAX, FLT_MAX, FLT_MAX), mx(-FLT_MAX, -FLT_MAX, -FLT_MAX);      // Scene::init's bounds, Scene.h:151-160
+    for (const Triangle& t : sd->triangles) for (const Vertex& v : t.vertices) {
+        mn = Vec3(std::min(mn.x, v.p.x), std::min(mn.y, v.p.y), std::min(mn.z, v.p.z));
+        mx = Vec3(std::max(mx.x, v.p.x), std::max(mx.y, v.p.y), std::max(mx.z, v.p.z));
+    }
+    viewcamera.movespeed = (mx - mn).length() * 0.05f;             // :385
+    scene->build();
+    return scene;
+}

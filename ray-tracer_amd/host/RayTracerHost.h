@@ -60,7 +60,11 @@ public:
     Vec3 operator-(const Vec3& v) const { return Vec3(x - v.x, y - v.y, z - v.z); }
     Vec3 operator*(float s) const { return Vec3(x * s, y * s, z * s); }
     float length() const { return sqrtf((x * x) + (y * y) + (z * z)); }
+    Vec3 normalize() const { float l = 1.0f / sqrtf((x * x) + (y * y) + (z * z)); return Vec3(x * l, y * l, z * l); }   // Core.h:173-177
+    float dot(const Vec3& v) const { return ((x * v.x) + (y * v.y) + (z * v.z)); }
+    Vec3 cross(const Vec3& v) const { return Vec3((y * v.z) - (z * v.y), (z * v.x) - (x * v.z), (x * v.y) - (y * v.x)); }
 };
+inline Vec3 Cross(const Vec3& a, const Vec3& b) { return a.cross(b); }
 
 struct Vertex { Vec3 p, normal; float u = 0, v = 0; };
 
@@ -163,14 +167,17 @@ public:
 class Camera {
 public:
     rtx_camera state{}; float width = 0, height = 0; Vec3 origin, viewDirection; float Afilm = 0;
+    float fov = 45.0f; int flip = 0; rtx_ctx* bound = nullptr;      // what lookAt was last called with; context to refresh on a move
     // loadScene's camera block (SceneLoader.h:342-360): perspective + lookAt, as one call
     void lookAt(Vec3 from, Vec3 to, Vec3 up, float fov, int w, int h, int flipX = 0)
     {
         const float f[3] = {from.x, from.y, from.z}, t[3] = {to.x, to.y, to.z}, u[3] = {up.x, up.y, up.z};
         rtxCheck(rtx_camera_look_at(&state, f, t, u, fov, w, h, flipX), "Camera::lookAt");
+        this->fov = fov; flip = flipX;
         width = (float)w; height = (float)h; Afilm = state.afilm;
         origin = Vec3(state.origin[0], state.origin[1], state.origin[2]);
         viewDirection = Vec3(state.view_dir[0], state.view_dir[1], state.view_dir[2]);
+        if (bound) rtxCheck(rtx_set_camera(bound, &state), "Camera::lookAt (device)");
     }
 };
 
@@ -225,6 +232,7 @@ public:
         }
         rtxCheck(rtx_upload_scene(ctx, &d), "Scene::build");
         rtxCheck(rtx_set_camera(ctx, &camera.state), "Scene::build (camera)");
+        camera.bound = ctx;
     }
     IntersectionData traverse(const Ray& ray)                               // Scene.h:137-141
     {
@@ -237,6 +245,46 @@ public:
         const float s[6] = {p1.x, p1.y, p1.z, p2.x, p2.y, p2.z}; uint8_t v = 0;
         rtxCheck(rtx_trace_visible(ctx, s, 1, &v), "Scene::visible");
         return v != 0;
+    }
+};
+
+// The fly-through camera of the reference's viewer, RTBase/SceneLoader.h:10-191. A move
+// recomputes the view (updateCamera -> Camera::updateView, :115-120) and hands it to the core;
+// the caller then calls RayTracer::clear() as RTBase/Main.cpp:158-162 does.
+class RTCamera {
+public:
+    Vec3 from, to, up; Camera* camera = nullptr; float movespeed = 1.0f, rotspeed = 5.0f;
+    void forward() { Vec3 dir = (to - from).normalize(); from = from + dir * movespeed; to = from + dir; }
+    void back() { Vec3 dir = (to - from).normalize(); from = from - dir * movespeed; to = from + dir; }
+    void right() { Vec3 dir = (to - from).normalize(); Vec3 r = Cross(dir, up); from = from + r * movespeed; to = from + dir; }
+    void left() { Vec3 dir = (to - from).normalize(); Vec3 r = Cross(dir, up); from = from - r * movespeed; to = from + dir; }
+    void flyUp() { Vec3 dir = up * movespeed; from = from + dir; to = to + dir; }
+    void flyDown() { Vec3 dir = up * movespeed; from = from - dir; to = to - dir; }
+    static Vec3 rotate(const Vec3& v, const Vec3& k, float angle)       // Rodrigues, as written at :79,:96,:112
+    {
+        float rad = (float)(angle * (M_PI / 180.0f));
+        float cosTheta = cosf(rad), sinTheta = sinf(rad);
+        return (v * cosTheta) + (k.cross(v) * sinTheta) + (k * (k.dot(v) * (1 - cosTheta)));
+    }
+    void yaw(float angle) { Vec3 dir = (to - from).normalize(); to = from + rotate(dir, up.normalize(), angle); }
+    void pitch(float angle) { Vec3 dir = (to - from).normalize(); to = from + rotate(dir, dir.cross(up).normalize(), angle); }
+    void roll(float angle) { Vec3 dir = (to - from).normalize(); up = rotate(up, dir, angle).normalize(); }
+    void updateCamera() { camera->lookAt(from, to, up, camera->fov, (int)camera->width, (int)camera->height, camera->flip); }
+    template <class WindowT> bool update(WindowT& canvas)                // key bindings of :122-190
+    {
+        bool change = false;
+        if (canvas.keyPressed('W')) { forward(); change = true; }
+        if (canvas.keyPressed('S')) { back(); change = true; }
+        if (canvas.keyPressed('A')) { left(); change = true; }
+        if (canvas.keyPressed('D')) { right(); change = true; }
+        if (canvas.keyPressed('E')) { flyUp(); change = true; }
+        if (canvas.keyPressed('Q')) { flyDown(); change = true; }
+        if (canvas.keyPressed(0x25)) { if (canvas.keyPressed(0x10)) roll(-rotspeed); else yaw(rotspeed); change = true; }     // VK_LEFT, VK_SHIFT
+        if (canvas.keyPressed(0x27)) { if (canvas.keyPressed(0x10)) roll(rotspeed); else yaw(-rotspeed); change = true; }     // VK_RIGHT
+        if (canvas.keyPressed(0x26)) { pitch(rotspeed); change = true; }                                                      // VK_UP
+        if (canvas.keyPressed(0x28)) { pitch(-rotspeed); change = true; }                                                     // VK_DOWN
+        if (change) updateCamera();
+        return change;
     }
 };
 

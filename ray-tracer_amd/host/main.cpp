@@ -3,7 +3,7 @@
 // renderMT() per progressive pass with the five console statistics, save the HDR when
 // totalSPP is reached. Flags of the reference: -scene, -outputFilename, -SPP
 // (RTBase/Main.cpp:104-115); added: -alg pt|lt|ir, -bounces N, -mis 0|1, -adaptive 0|1,
-// -seed N, -png file, -dumpFilm file (raw float sums), -dumpScene file, -device N, -quiet 1.
+// -seed N, -png file, -dumpFilm file (raw float sums), -dumpScene file, -orbit degrees (yaw the view first), -device N, -quiet 1.
 //
 // -scene takes what the reference takes, a directory with scene.json + .gem meshes + textures
 // (GemScene.h), or an ".rtxs" dump (see SceneArrays.save in the Python package). -dumpScene file
@@ -142,7 +142,7 @@ static Scene* buildScene(const gem::SceneData& sd, int device)
 int main(int argc, char* argv[])
 {
     SETTINGS settings = createSettings();
-    std::string sceneName, filename = "render_GI.hdr", png, dump, dumpScene; int device = 0; bool quiet = false;
+    std::string sceneName, filename = "render_GI.hdr", png, dump, dumpScene; int device = 0; bool quiet = false; float orbitDeg = 0.0f;
     std::unordered_map<std::string, std::string> args;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -164,6 +164,7 @@ int main(int argc, char* argv[])
         else if (p.first == "-dumpScene") dumpScene = p.second;
         else if (p.first == "-device") device = std::stoi(p.second);
         else if (p.first == "-quiet") quiet = std::stoi(p.second) != 0;
+        else if (p.first == "-orbit") orbitDeg = std::stof(p.second);
         else std::cerr << "Warning: unknown flag '" << p.first << "'\n";
     }
     if (sceneName.empty()) { std::cerr << "usage: rt_headless -scene <scene directory | file.rtxs> [-outputFilename out.hdr] [-SPP n] ...\n"; return 2; }
@@ -173,6 +174,9 @@ int main(int argc, char* argv[])
         loadSceneData(sceneName, data);
         if (!dumpScene.empty()) { dumpRtxs(dumpScene, data); std::cout << "Wrote " << dumpScene << " (" << data.triangles.size() << " triangles, " << data.materials.size() << " materials)" << std::endl; return 0; }
         Scene* scene = buildScene(data, device);
+        RTCamera viewcamera; viewcamera.from = data.from; viewcamera.to = data.to; viewcamera.up = data.up; viewcamera.camera = &scene->camera;
+        // -orbit deg: what holding an arrow key does in the viewer (SceneLoader.h:159-173 -> yaw -> updateCamera), before the render starts
+        if (orbitDeg != 0.0f) { viewcamera.yaw(orbitDeg); viewcamera.updateCamera(); }
         GamesEngineeringBase::Window canvas;
         canvas.create((unsigned int)scene->camera.width, (unsigned int)scene->camera.height, "Tracer", 1.0f);
         RayTracer rt;

@@ -89,3 +89,29 @@ def test_gem_scene_directory_renders_like_its_dump(tmp_path, pkg, lib, core, sce
     # normals are re-normalised by the loader (last-bit differences in shading normals)
     err = np.abs(film - f2) / np.maximum(np.abs(f2), 1e-2)
     assert np.mean((err > 1e-3).any(axis=-1)) < 0.01
+
+
+def test_fly_through_camera_yaw(tmp_path, pkg, lib, core, scenes):
+    """RTCamera::yaw + updateCamera (SceneLoader.h:68-83, 115-120) re-aim the device camera:
+    the film after -orbit equals a render with the rotated look-at point."""
+    sc, kw = scenes.cornell_box("diffuse"), scenes.cornell_camera()
+    w, h, spp, deg = 64, 48, 4, 20.0
+    path = str(tmp_path / "box.rtxs")
+    sc.save(path, kw["frm"], kw["to"], kw["up"], kw["fov"], w, h)
+    dump = str(tmp_path / "film.bin")
+    out = subprocess.run([APP, "-scene", path, "-outputFilename", str(tmp_path / "o.hdr"), "-SPP", str(spp), "-dumpFilm", dump, "-adaptive", "0",
+                          "-seed", "3", "-orbit", str(deg), "-quiet", "1"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    film = np.frombuffer(open(dump, "rb").read(), np.float32, w * h * 3, 12).reshape(h, w, 3)
+    frm, to, up = (np.array(kw[k], np.float32) for k in ("frm", "to", "up"))
+    d = (to - frm) / np.linalg.norm(to - frm); k = up / np.linalg.norm(up)
+    rad = np.float32(deg * (np.pi / 180.0)); c, s = np.cos(rad), np.sin(rad)
+    rot = d * c + np.cross(k, d) * s + k * (np.dot(k, d) * (1 - c))
+    core.upload_scene(sc)
+    core.set_camera(pkg.look_at(lib, tuple(frm), tuple((frm + rot).astype(np.float32)), tuple(up), kw["fov"], w, h))
+    core.set_settings(pkg.make_settings(total_spp=spp, init_spp=spp, seed=3, num_threads=20))
+    core.clear(); core.render_passes(spp)
+    f2, _, _ = core.film()
+    assert not np.allclose(f2, 0)
+    err = np.abs(film - f2) / np.maximum(np.abs(f2), 1e-2)
+    assert np.mean((err > 1e-3).any(axis=-1)) < 0.02
