@@ -225,3 +225,27 @@ def test_two_sidedness_of_the_remaining_bsdfs(pkg, lib, orc, scenes):
         facing = float(np.dot(s_n, -gn))                             # wo = -d = -gn
         assert (facing > 0) == flips, (mat, facing)
     osc.close()
+
+
+def test_oracle_reproduces_frozen_path_vectors(pkg, lib, orc, scenes):
+    """tests/golden/path_vectors.npz (make_path_vectors.py): the oracle of today gives the hits,
+    visibility bits, per-sample films and tile targets that were frozen."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_path_vectors", os.path.join(os.path.dirname(__file__), "golden", "make_path_vectors.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "path_vectors.npz"))
+    rays, seg = gen.inputs(pkg, scenes)
+    osc = orc.scene(scenes.soup(2000, seed=77, size=0.08))
+    hits = osc.trace_closest(rays, threads=4)
+    assert np.array_equal(hits["id"], gold["hit_id"]) and np.array_equal(hits["t"], gold["hit_t"])
+    assert np.array_equal(np.stack([hits["alpha"], hits["beta"], hits["gamma"]], 1), gold["hit_bary"])
+    assert np.array_equal(osc.trace_visible(seg, threads=4), gold["visible"])
+    osc.close()
+    osc = orc.scene(scenes.cornell_box("mixed"))
+    osc.set_camera(pkg.look_at(lib, width=48, height=36, **scenes.cornell_camera()))
+    r = osc.renderer(pkg.make_settings(total_spp=64, init_spp=3, adaptive_sampling=1, seed=11), threads=2, counter_rng=True)
+    for k in range(3):
+        r.render_passes(1)
+        assert np.allclose(r.film()[0], gold["pt_films"][k], rtol=1e-6, atol=1e-7), f"pass {k + 1}"
+    assert np.array_equal(r.film()[2], gold["tile_targets"])
+    r.close(); osc.close()
