@@ -100,44 +100,64 @@ __device__ inline void bin_add(uint32_t* e, const Prep& t)
     atomicAdd(&e[6], 1u);
 }
 
-// per slot: drop the triangle into its bin on each axis. A workgroup whose slots all belong to
-// one node collects in LDS first (the top levels would otherwise queue on a handful of addresses).
+// per slot: drop the triangle into its bin on each axis. A workgroup walks kChunks consecutive
+// chunks of 256 slots; while they all belong to one node it collects in LDS and flushes once (the
+// top levels would otherwise queue on a handful of addresses), mixed chunks go straight to memory.
+constexpr int kChunks = 16;
 __global__ __launch_bounds__(kBlk) void k_bin(const Node* __restrict__ nodes, const uint32_t* __restrict__ slot_node, const uint32_t* __restrict__ idx,
                                               const Prep* __restrict__ prep, const float* __restrict__ planes, uint32_t* bins, uint32_t n)
 {
     __shared__ uint32_t s_bins[kBinWords];
-    __shared__ uint32_t s_first, s_uniform;
-    const uint32_t i = blockIdx.x * kBlk + threadIdx.x;
-    const uint32_t node = i < n ? slot_node[i] : kNoNode;
-    if (threadIdx.x == 0) { s_first = node; s_uniform = 1; }
-    __syncthreads();
-    if (i < n && node != s_first) s_uniform = 0;
-    for (int k = threadIdx.x; k < kBinWords; k += kBlk) { const int f = k % 7; s_bins[k] = f < 3 ? fkey(FLT_MAX) : f < 6 ? fkey(-FLT_MAX) : 0u; }
-    __syncthreads();
-    const bool uniform = s_uniform != 0;
-    const bool live = i < n && node != kNoNode && nodes[node].active;
-    if (live) {
-        const Node& nd = nodes[node];
-        const Prep t = prep[idx[i]];
-        const float* pl = planes + (size_t)nd.slot * 45;
-        uint32_t* dst = uniform ? s_bins : bins + (size_t)nd.slot * kBinWords;
-        for (int a = 0; a < 3; a++) {
-            const float c = t.centre[a];
-            int k = 0;
-            while (k < kBins && !(c < pl[a * kBins + k])) k++;                                              // Geometry.h:327
-            bin_add(dst + (a * (kBins + 1) + k) * 7, t);
-        }
-    }
-    __syncthreads();
-    if (uniform && s_first != kNoNode && nodes[s_first].active) {
-        uint32_t* dst = bins + (size_t)nodes[s_first].slot * kBinWords;
+    __shared__ uint32_t s_first, s_uniform, s_held;      // s_held: node whose bins are in LDS (kNoNode: none)
+    auto clear = [&]() { for (int k = threadIdx.x; k < kBinWords; k += kBlk) { const int f = k % 7; s_bins[k] = f < 3 ? fkey(FLT_MAX) : f < 6 ? fkey(-FLT_MAX) : 0u; } };
+    auto flush = [&](uint32_t node) {
+        uint32_t* dst = bins + (size_t)nodes[node].slot * kBinWords;
         for (int k = threadIdx.x; k < kBinWords; k += kBlk) {
             const int f = k % 7; const uint32_t v = s_bins[k];
             if (f < 3) { if (v != fkey(FLT_MAX)) atomicMin(&dst[k], v); }
             else if (f < 6) { if (v != fkey(-FLT_MAX)) atomicMax(&dst[k], v); }
             else if (v) atomicAdd(&dst[k], v);
         }
+    };
+    if (threadIdx.x == 0) s_held = kNoNode;
+    clear();
+    __syncthreads();
+    for (int c = 0; c < kChunks; c++) {
+        const uint32_t base = (blockIdx.x * (uint32_t)kChunks + (uint32_t)c) * kBlk;
+        if (base >= n) break;
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t node = i < n ? slot_node[i] : kNoNode;
+        if (threadIdx.x == 0) { s_first = node; s_uniform = 1; }
+        __syncthreads();
+        if (i < n && node != s_first) s_uniform = 0;
+        __syncthreads();
+        const bool uniform = s_uniform != 0 && s_first != kNoNode && nodes[s_first].active;
+        const uint32_t held = s_held;
+        __syncthreads();                                             // everyone has read s_held before it changes below
+        if (held != kNoNode && !(uniform && s_first == held)) {      // the LDS bins belong to another node: write them out
+            flush(held);
+            __syncthreads();
+            clear();
+            if (threadIdx.x == 0) s_held = kNoNode;
+            __syncthreads();
+        }
+        if (uniform && threadIdx.x == 0) s_held = s_first;
+        const bool live = i < n && node != kNoNode && nodes[node].active;
+        if (live) {
+            const Node& nd = nodes[node];
+            const Prep t = prep[idx[i]];
+            const float* pl = planes + (size_t)nd.slot * 45;
+            for (int a = 0; a < 3; a++) {
+                const float cc = t.centre[a];
+                int k = 0;
+                while (k < kBins && !(cc < pl[a * kBins + k])) k++;                                          // Geometry.h:327
+                if (uniform) bin_add(s_bins + (a * (kBins + 1) + k) * 7, t);
+                else bin_add(bins + (size_t)nd.slot * kBinWords + (a * (kBins + 1) + k) * 7, t);
+            }
+        }
+        __syncthreads();
     }
+    if (s_held != kNoNode) flush(s_held);
 }
 
 struct Box { float mn[3], mx[3]; uint32_t n; };
@@ -177,7 +197,7 @@ __global__ void k_best(Node* nodes, Level lv, const float* __restrict__ planes, 
     n.axis = bestAxis; n.pos = bestPos;
 }
 
-// per slot: 1 when createSplit moves the triangle to the front (Geometry.h:351-352); first "false" per node
+// per slot: 1 when createSplit moves the triangle to the front (Geometry.h:351-352)
 __global__ __launch_bounds__(kBlk) void k_flags(Node* nodes, const uint32_t* __restrict__ slot_node, const uint32_t* __restrict__ idx, const Prep* __restrict__ prep,
                                                 uint32_t* flags, uint32_t n)
 {
@@ -188,9 +208,21 @@ __global__ __launch_bounds__(kBlk) void k_flags(Node* nodes, const uint32_t* __r
     uint32_t f = 0;
     if (node != kNoNode && nodes[node].active) {
         f = prep[idx[i]].centre[nodes[node].axis] > nodes[node].pos ? 1u : 0u;
-        if (!f) atomicMin(&nodes[node].first_false, i);
     }
     flags[i] = f;
+}
+
+// per slot: the first "false" of a node is the one slot that is false while everything before it in
+// the node is true — exactly one writer per node, no atomics
+__global__ __launch_bounds__(kBlk) void k_first_false(Node* nodes, const uint32_t* __restrict__ slot_node, const uint32_t* __restrict__ flags,
+                                                      const uint32_t* __restrict__ tpre, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * kBlk + threadIdx.x;
+    if (i >= n || flags[i]) return;
+    const uint32_t node = slot_node[i];
+    if (node == kNoNode || !nodes[node].active) return;
+    const uint32_t start = nodes[node].start;
+    if (tpre[i] - tpre[start] == i - start) nodes[node].first_false = i;
 }
 
 // exclusive prefix sum over n + 1 flags: per-block scan, scan of the block totals, add back
@@ -367,12 +399,13 @@ inline hipError_t build_bvh2_device(const std::vector<TriPrep>& tris, const floa
         RTX_DB(hipStreamSynchronize(stream));
         if (hc[0] == 0) break;                                                      // nothing left to split
         uint32_t* idx_in = b_idx[cur].as<uint32_t>(); uint32_t* idx_out = b_idx[cur ^ 1].as<uint32_t>();
-        hipLaunchKernelGGL(k_bin, gridN, blk, 0, stream, nodes, b_slot.as<uint32_t>(), idx_in, b_prep.as<Prep>(), b_planes.as<float>(), b_bins.as<uint32_t>(), n);
+        hipLaunchKernelGGL(k_bin, dim3((n + kBlk * kChunks - 1) / (kBlk * kChunks)), blk, 0, stream, nodes, b_slot.as<uint32_t>(), idx_in, b_prep.as<Prep>(), b_planes.as<float>(), b_bins.as<uint32_t>(), n);
         hipLaunchKernelGGL(k_best, gridL, blkL, 0, stream, nodes, lv, b_planes.as<float>(), b_bins.as<uint32_t>());
         hipLaunchKernelGGL(k_flags, gridN1, blk, 0, stream, nodes, b_slot.as<uint32_t>(), idx_in, b_prep.as<Prep>(), b_flags.as<uint32_t>(), n);
         hipLaunchKernelGGL(k_scan_blocks, gridN1, blk, 0, stream, b_flags.as<uint32_t>(), b_tpre.as<uint32_t>(), b_sums.as<uint32_t>(), n + 1);
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, b_sums.as<uint32_t>(), scanBlocks);
         hipLaunchKernelGGL(k_scan_add, gridN1, blk, 0, stream, b_tpre.as<uint32_t>(), b_sums.as<uint32_t>(), n + 1);
+        hipLaunchKernelGGL(k_first_false, gridN, blk, 0, stream, nodes, b_slot.as<uint32_t>(), b_flags.as<uint32_t>(), b_tpre.as<uint32_t>(), n);
         hipLaunchKernelGGL(k_links, gridN, blk, 0, stream, nodes, b_slot.as<uint32_t>(), b_flags.as<uint32_t>(), b_tpre.as<uint32_t>(), b_link[0].as<uint32_t>(), n);
         int lk = 0;
         for (uint32_t span = 1; span < hc[1]; span <<= 1) {                         // chains are shorter than the largest node
