@@ -6,6 +6,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <deque>
+#include <functional>
 #include <thread>
 
 namespace rtx {
@@ -136,21 +137,41 @@ struct Builder {
 
 } // namespace
 
+// fn(begin, end) over [0, n) on up to 16 threads (RTX_BUILD_THREADS overrides)
+void parallel_ranges(uint64_t n, const std::function<void(uint64_t, uint64_t)>& fn)
+{
+    int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("RTX_BUILD_THREADS")) threads = std::max(1, atoi(e));
+    if (n < 100000 || threads == 1) { fn((uint64_t)0, n); return; }
+    std::vector<std::thread> pool;
+    const uint64_t per = (n + threads - 1) / threads;
+    for (int t = 0; t < threads; t++) { const uint64_t b = t * per, e = std::min(n, b + per); if (b < e) pool.emplace_back([=]() { fn(b, e); }); }
+    for (auto& th : pool) th.join();
+}
+
 void prepare_triangles(const float* p, uint64_t n, std::vector<TriPrep>& out, float smin[3], float smax[3])
 {
     out.resize(n);
+    parallel_ranges(n, [&](uint64_t b, uint64_t e) {
+        for (uint64_t i = b; i < e; i++) {
+            const float* v0 = p + i * 9; const float* v1 = v0 + 3; const float* v2 = v0 + 6;
+            TriPrep& t = out[i];
+            for (int a = 0; a < 3; a++) {
+                t.e1[a] = v0[a] - v2[a];
+                t.e2[a] = v1[a] - v2[a];
+                t.v2[a] = v2[a];
+                t.maxP[a] = refMax(v0[a], refMax(v1[a], v2[a]));
+                t.minP[a] = refMin(v0[a], refMin(v1[a], v2[a]));
+                t.centre[a] = t.minP[a] + (t.maxP[a] - t.minP[a]) * 0.5f;
+            }
+        }
+    });
+    // Scene::init extends the scene box by the three vertices of every triangle in turn, Scene.h:156-158
+    // (kept sequential: the sign of a zero bound depends on the order)
     for (int a = 0; a < 3; a++) { smin[a] = FLT_MAX; smax[a] = -FLT_MAX; }
     for (uint64_t i = 0; i < n; i++) {
         const float* v0 = p + i * 9; const float* v1 = v0 + 3; const float* v2 = v0 + 6;
-        TriPrep& t = out[i];
         for (int a = 0; a < 3; a++) {
-            t.e1[a] = v0[a] - v2[a];
-            t.e2[a] = v1[a] - v2[a];
-            t.v2[a] = v2[a];
-            t.maxP[a] = refMax(v0[a], refMax(v1[a], v2[a]));
-            t.minP[a] = refMin(v0[a], refMin(v1[a], v2[a]));
-            t.centre[a] = t.minP[a] + (t.maxP[a] - t.minP[a]) * 0.5f;
-            // Scene::init extends the scene box by the three vertices in turn, Scene.h:156-158
             smax[a] = refMax(refMax(refMax(smax[a], v0[a]), v1[a]), v2[a]);
             smin[a] = refMin(refMin(refMin(smin[a], v0[a]), v1[a]), v2[a]);
         }

@@ -10,6 +10,7 @@
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 namespace rtx {
@@ -63,6 +64,9 @@ struct Bvh4 {
     uint32_t depth = 0;            // levels of Node4 below (and including) the root
     float root_min[3], root_max[3];
 };
+
+// fn(begin, end) over [0, n) on up to 16 host threads
+void parallel_ranges(uint64_t n, const std::function<void(uint64_t, uint64_t)>& fn);
 
 void prepare_triangles(const float* positions, uint64_t n, std::vector<TriPrep>& out,
                        float scene_min[3], float scene_max[3]);

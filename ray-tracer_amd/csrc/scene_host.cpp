@@ -167,7 +167,7 @@ std::string prepare_scene(const rtx_scene_desc& d, HostScene& hs, const Bvh2Buil
     float smin[3], smax[3];
     prepare_triangles(d.positions, d.n_triangles, prep, smin, smax);
     hs.shade.assign(d.n_triangles, TriShade{});
-    for (uint64_t i = 0; i < d.n_triangles; i++) {
+    parallel_ranges(d.n_triangles, [&](uint64_t rb, uint64_t re) { for (uint64_t i = rb; i < re; i++) {
         TriShade& s = hs.shade[i];
         std::memcpy(s.n0, d.normals + i * 9, 36);
         std::memcpy(s.uv0, d.uvs + i * 6, 24);
@@ -178,7 +178,7 @@ std::string prepare_scene(const rtx_scene_desc& d, HostScene& hs, const Bvh2Buil
         s.gsign = dot3(f3(s.n0), n) > 0 ? 1.0f : -1.0f;                                            // Geometry.h:158-161
         s.area = len3(c) * 0.5f;
         s.material = d.material_index[i];
-    }
+    } });
 
     auto t1 = std::chrono::steady_clock::now();
     if (build) { if (!build(prep, smin, smax, hs.bvh2)) return "device BVH build failed"; }
@@ -191,13 +191,13 @@ std::string prepare_scene(const rtx_scene_desc& d, HostScene& hs, const Bvh2Buil
                 std::chrono::duration<float, std::milli>(t1 - t0).count(), build ? "device" : "host",
                 std::chrono::duration<float, std::milli>(t2 - t1).count(), std::chrono::duration<float, std::milli>(t3 - t2).count());
     hs.tris.resize(d.n_triangles);
-    for (uint64_t p = 0; p < d.n_triangles; p++) {
+    parallel_ranges(d.n_triangles, [&](uint64_t rb, uint64_t re) { for (uint64_t p = rb; p < re; p++) {
         const uint32_t id = hs.bvh4.order[p]; const TriPrep& t = prep[id]; TriIsect& o = hs.tris[p];
         float idf; std::memcpy(&idf, &id, 4);
         o.q0 = make_float4(t.e1[0], t.e1[1], t.e1[2], idf);
         o.q1 = make_float4(t.e2[0], t.e2[1], t.e2[2], 0.0f);
         o.q2 = make_float4(t.v2[0], t.v2[1], t.v2[2], 0.0f);
-    }
+    } });
 
     // scene bounding sphere, SceneLoader.h:387-388
     if (d.n_triangles) {
