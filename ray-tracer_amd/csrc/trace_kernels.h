@@ -8,9 +8,9 @@
 namespace rtx {
 
 constexpr float kEpsilon = 0.001f;    // EPSILON, RTBase/Geometry.h:54
-constexpr int kRefill = 16;           // idle lanes that trigger a fetch of new rays
+constexpr int kRefill = 20;           // idle lanes that trigger a fetch of new rays
 constexpr int kTriUnroll = 4;         // leaf triangles whose loads are issued together
-constexpr int kLeafLanes = 24;        // the wave stops descending and tests triangles once this many lanes hold a leaf
+constexpr int kLeafLanes = 28;        // the wave stops descending and tests triangles once this many lanes hold a leaf
 
 __device__ __forceinline__ uint32_t global_thread() { return blockIdx.x * kBlock + threadIdx.x; }
 
