@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
-NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 128, 48, 24, 20
+NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 128, 36, 24, 20
 
 
 def main():

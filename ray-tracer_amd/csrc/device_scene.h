@@ -8,11 +8,11 @@
 
 namespace rtx {
 
-// One triangle in leaf order, 48 bytes = three 16-byte loads:
-//   q0 = e1.xyz, original triangle index (bit pattern)
-//   q1 = e2.xyz, 0
-//   q2 = v2.xyz, 0
-struct TriIsect { float4 q0, q1, q2; };
+// One triangle in leaf order: the nine floats Triangle::rayIntersect reads (RTBase/Geometry.h:95-126),
+// 36 bytes and nothing else — the texture path moves a fixed number of bytes per lane and clock, so
+// padding and the id (needed once per ray, kept in DeviceScene::tri_ids) would cost traversal time.
+struct TriIsect { float e1[3], e2[3], v2[3]; };
+static_assert(sizeof(TriIsect) == 36, "packed triangle record");
 
 // Shading attributes per ORIGINAL triangle index, 96 bytes (Triangle members read by
 // Scene::calculateShadingData, RTBase/Scene.h:183-213, and by the lights).
@@ -66,6 +66,7 @@ struct DeviceScene {
     const float4* nodes4;        // Node4 array as float4[8] per node
     const float4* nodes2;        // Node2Dev array as float4[2] per node
     const TriIsect* tris;        // leaf order
+    const uint32_t* tri_ids;     // leaf order -> original triangle index
     const TriShade* shade;       // original order
     const MaterialDev* materials;
     const float* texels;         // all textures, RGB triples

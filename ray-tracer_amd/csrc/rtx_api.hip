@@ -146,6 +146,7 @@ int rtx_upload_scene(rtx_ctx* c, const rtx_scene_desc* d)
     if ((rc = upload(c->b_nodes4, h.bvh4.nodes, s))) return rc;
     if ((rc = upload(c->b_nodes2, h.bvh4.nodes2, s))) return rc;
     if ((rc = upload(c->b_tris, h.tris, s))) return rc;
+    if ((rc = upload(c->b_tri_ids, h.bvh4.order, s))) return rc;
     if ((rc = upload(c->b_shade, h.shade, s))) return rc;
     if ((rc = upload(c->b_materials, h.materials, s))) return rc;
     if ((rc = upload(c->b_texels, h.texels, s))) return rc;
@@ -156,7 +157,7 @@ int rtx_upload_scene(rtx_ctx* c, const rtx_scene_desc* d)
     HIP_TRY(hipStreamSynchronize(s));
 
     DeviceScene& ds = c->dscene;
-    ds.nodes4 = c->b_nodes4.as<float4>(); ds.nodes2 = c->b_nodes2.as<float4>(); ds.tris = c->b_tris.as<TriIsect>();
+    ds.nodes4 = c->b_nodes4.as<float4>(); ds.nodes2 = c->b_nodes2.as<float4>(); ds.tris = c->b_tris.as<TriIsect>(); ds.tri_ids = c->b_tri_ids.as<uint32_t>();
     ds.shade = c->b_shade.as<TriShade>(); ds.materials = c->b_materials.as<MaterialDev>(); ds.texels = c->b_texels.as<float>();
     ds.lights = c->b_lights.as<LightDev>(); ds.n_lights = (uint32_t)h.lights.size(); ds.n_tris = (uint32_t)h.tris.size();
     for (int a = 0; a < 3; a++) { ds.root_min[a] = h.bvh4.root_min[a]; ds.root_max[a] = h.bvh4.root_max[a]; ds.bg_emission[a] = h.bg_emission[a]; ds.scene_centre[a] = h.scene_centre[a]; }

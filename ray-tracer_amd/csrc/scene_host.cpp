@@ -193,10 +193,7 @@ std::string prepare_scene(const rtx_scene_desc& d, HostScene& hs, const Bvh2Buil
     hs.tris.resize(d.n_triangles);
     parallel_ranges(d.n_triangles, [&](uint64_t rb, uint64_t re) { for (uint64_t p = rb; p < re; p++) {
         const uint32_t id = hs.bvh4.order[p]; const TriPrep& t = prep[id]; TriIsect& o = hs.tris[p];
-        float idf; std::memcpy(&idf, &id, 4);
-        o.q0 = make_float4(t.e1[0], t.e1[1], t.e1[2], idf);
-        o.q1 = make_float4(t.e2[0], t.e2[1], t.e2[2], 0.0f);
-        o.q2 = make_float4(t.v2[0], t.v2[1], t.v2[2], 0.0f);
+        for (int a = 0; a < 3; a++) { o.e1[a] = t.e1[a]; o.e2[a] = t.e2[a]; o.v2[a] = t.v2[a]; }
     } });
 
     // scene bounding sphere, SceneLoader.h:387-388

@@ -37,7 +37,7 @@ __device__ __forceinline__ rtx_hit make_hit(const DeviceScene& sc, const HitRec&
 {
     rtx_hit h;
     if (best.pos != 0xFFFFFFFFu) {
-        h.id = __float_as_uint(sc.tris[best.pos].q0.w);
+        h.id = sc.tri_ids[best.pos];
         h.t = best.t; h.alpha = best.u; h.beta = best.v; h.gamma = 1.0f - (best.u + best.v);   // Geometry.h:537-541
     } else { h.id = 0xFFFFFFFFu; h.t = FLT_MAX; h.alpha = 0; h.beta = 0; h.gamma = 0; }
     return h;

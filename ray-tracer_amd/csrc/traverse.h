@@ -43,8 +43,8 @@ struct TravCount { uint32_t nodes, tris; };
 __device__ __forceinline__ bool tri_test(const TriIsect& T, float ox, float oy, float oz, float dx, float dy, float dz,
                                          float& t, float& u, float& v)
 {
-    const float e1x = T.q0.x, e1y = T.q0.y, e1z = T.q0.z;
-    const float e2x = T.q1.x, e2y = T.q1.y, e2z = T.q1.z;
+    const float e1x = T.e1[0], e1y = T.e1[1], e1z = T.e1[2];
+    const float e2x = T.e2[0], e2y = T.e2[1], e2z = T.e2[2];
     // p = Cross(dir, e2)
     float px = (dy * e2z) - (dz * e2y);
     float py = (dz * e2x) - (dx * e2z);
@@ -52,7 +52,7 @@ __device__ __forceinline__ bool tri_test(const TriIsect& T, float ox, float oy, 
     float det = ((px * e1x) + (py * e1y)) + (pz * e1z);
     if (fabsf(det) < kTriEps) return false;
     float invDet = 1.0f / det;
-    float Tx = ox - T.q2.x, Ty = oy - T.q2.y, Tz = oz - T.q2.z;
+    float Tx = ox - T.v2[0], Ty = oy - T.v2[1], Tz = oz - T.v2[2];
     u = (((Tx * px) + (Ty * py)) + (Tz * pz)) * invDet;
     if ((u < 0 && fabsf(u) > kTriEps) || (u > 1 && fabsf(u - 1) > kTriEps)) return false;
     // q = Cross(T, e1)
