@@ -262,20 +262,29 @@ __device__ __forceinline__ uint32_t step_inner(const DeviceScene& sc, LaneStack<
     const float4 cf = np[6];
     if (COUNT) cnt->nodes++;
     const uint32_t ref[4] = {__float_as_uint(cf.x), __float_as_uint(cf.y), __float_as_uint(cf.z), __float_as_uint(cf.w)};
-    const float lx[4] = {lox.x, lox.y, lox.z, lox.w}, ly[4] = {loy.x, loy.y, loy.z, loy.w}, lz[4] = {loz.x, loz.y, loz.z, loz.w};
-    const float hx[4] = {hix.x, hix.y, hix.z, hix.w}, hy[4] = {hiy.x, hiy.y, hiy.z, hiy.w}, hz[4] = {hiz.x, hiz.y, hiz.z, hiz.w};
     // all four child references are needed whatever the boxes say: tested up front (and combined
     // without short-circuit below) so that their load stays with the other six instead of becoming
     // a dependent load behind the first box test
     const bool valid[4] = {ref[0] != kEmptySlot, ref[1] != kEmptySlot, ref[2] != kEmptySlot, ref[3] != kEmptySlot};
+    // (plane - origin) * reciprocal for two children at a time: CDNA's packed fp32 add / mul take the
+    // register pairs as the loads deliver them and round each half exactly like the scalar forms
+    typedef float Pair __attribute__((ext_vector_type(2)));
+    const Pair O[3] = {{ox, ox}, {oy, oy}, {oz, oz}}, I[3] = {{ix, ix}, {iy, iy}, {iz, iz}};
+    const float4 lo4[3] = {lox, loy, loz}, hi4[3] = {hix, hiy, hiz};
+    float t0[3][4], t1[3][4];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const Pair l01 = {lo4[a].x, lo4[a].y}, l23 = {lo4[a].z, lo4[a].w}, h01 = {hi4[a].x, hi4[a].y}, h23 = {hi4[a].z, hi4[a].w};
+        const Pair a01 = (l01 - O[a]) * I[a], a23 = (l23 - O[a]) * I[a], b01 = (h01 - O[a]) * I[a], b23 = (h23 - O[a]) * I[a];
+        t0[a][0] = a01.x; t0[a][1] = a01.y; t0[a][2] = a23.x; t0[a][3] = a23.y;
+        t1[a][0] = b01.x; t1[a][1] = b01.y; t1[a][2] = b23.x; t1[a][3] = b23.y;
+    }
     float key[4]; uint32_t kref[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        float t0x = (lx[c] - ox) * ix, t1x = (hx[c] - ox) * ix;
-        float t0y = (ly[c] - oy) * iy, t1y = (hy[c] - oy) * iy;
-        float t0z = (lz[c] - oz) * iz, t1z = (hz[c] - oz) * iz;
-        float tentry = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
-        float texit = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+        // no NaN can occur here (finite reciprocals), so plain min/max equal the reference's selects
+        float tentry = fmaxf(fmaxf(fminf(t0[0][c], t1[0][c]), fminf(t0[1][c], t1[1][c])), fminf(t0[2][c], t1[2][c]));
+        float texit = fminf(fminf(fmaxf(t0[0][c], t1[0][c]), fmaxf(t0[1][c], t1[1][c])), fmaxf(t0[2][c], t1[2][c]));
         const bool hit = valid[c] & !(tentry > texit || texit < 0) & !(tentry > bound);
         key[c] = hit ? tentry : FLT_MAX;
         kref[c] = hit ? ref[c] : kEmptySlot;
