@@ -269,21 +269,24 @@ int rtx_render_passes(rtx_ctx* c, int n)
     for (int l = 1; l < lanes; l++)
         if (!c->wf[l]) { int rc = wavefront_alloc(c, l); if (rc) return fail(rc, "wavefront buffers: allocation failed"); }
     if (c->spill_lanes < lanes) { c->spill_lanes = lanes; int rc = ensure_spill(c); if (rc) return rc; }
+    // lane 0 runs on the caller's stream itself, the others on streams of their own
+    hipStream_t ls[kPipeline];
+    for (int l = 0; l < lanes; l++) ls[l] = l == 0 ? c->stream : c->pipe_stream[l];
     HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
-    for (int l = 0; l < lanes; l++) HIP_TRY(hipStreamWaitEvent(c->pipe_stream[l], c->ev_fork, 0));
+    for (int l = 1; l < lanes; l++) HIP_TRY(hipStreamWaitEvent(ls[l], c->ev_fork, 0));
     const rtx_settings& st = c->settings;
     for (int i = 0; i < n; i++) {
         const int l = i % lanes;
-        int rc = wavefront_render_pass(c, l, c->pipe_stream[l], i > 0 ? c->pipe_film[(i - 1) % lanes] : nullptr, c->pipe_film[l]);
+        int rc = wavefront_render_pass(c, l, ls[l], i > 0 ? c->pipe_film[(i - 1) % lanes] : nullptr, c->pipe_film[l]);
         if (rc) return fail(rc, "render pass failed: %s", hipGetErrorString(hipGetLastError()));
         if (c->spp == (int)st.init_spp && st.algorithm != RTX_AL_LIGHT_TRACE && st.shard_mode != 2) {
             // the adaptive sample targets were just computed on this lane: later passes read them
-            HIP_TRY(hipEventRecord(c->ev_tiles, c->pipe_stream[l]));
-            for (int k = 0; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(c->pipe_stream[k], c->ev_tiles, 0));
+            HIP_TRY(hipEventRecord(c->ev_tiles, ls[l]));
+            for (int k = 0; k < lanes; k++) if (k != l) HIP_TRY(hipStreamWaitEvent(ls[k], c->ev_tiles, 0));
         }
     }
-    for (int l = 0; l < lanes; l++) {
-        HIP_TRY(hipEventRecord(c->pipe_done[l], c->pipe_stream[l]));
+    for (int l = 1; l < lanes; l++) {
+        HIP_TRY(hipEventRecord(c->pipe_done[l], ls[l]));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->pipe_done[l], 0));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
