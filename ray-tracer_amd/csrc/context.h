@@ -58,6 +58,9 @@ struct rtx_ctx {
     int pipeline = 3;                                  // passes rtx_render_passes keeps in flight (RTX_PIPELINE); 3 + the caller's stream fit the 4 hardware queues
     int spill_lanes = 1;                               // traversal-stack slabs in b_spill
     hipStream_t pipe_stream[rtx::kPipeline] = {};
+    hipStream_t aux_stream[rtx::kPipeline] = {};       // per lane: shadow rays of depth d run beside the closest hits of depth d + 1
+    hipEvent_t ev_shade[rtx::kPipeline] = {}, ev_shadow[rtx::kPipeline] = {};
+    int overlap = 1;                                   // used when a call renders one pass at a time; RTX_OVERLAP=0 keeps a pass on one stream
     hipEvent_t pipe_film[rtx::kPipeline] = {}, pipe_done[rtx::kPipeline] = {}, ev_fork = nullptr, ev_tiles = nullptr;
 
     rtx_stats stats{};

@@ -83,7 +83,11 @@ int rtx_create(rtx_ctx** out, int device)
         HIP_TRY(hipStreamCreateWithFlags(&c->pipe_stream[i], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&c->pipe_film[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->pipe_done[i], hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_shade[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_shadow[i], hipEventDisableTiming));
     }
+    if (const char* v = getenv("RTX_OVERLAP")) c->overlap = atoi(v) != 0;
     if (const char* v = getenv("RTX_PIPELINE")) c->pipeline = std::max(1, std::min(kPipeline, atoi(v)));
     HIP_TRY(c->b_counters.ensure(4 * (1 + 2) * kWorkSlotWords));   // instrumentation counters, then the work-counter slots of the closest-hit and visibility launches
     // RayTracer's defaults, RTBase/Settings.h:40-61
@@ -106,6 +110,9 @@ void rtx_destroy(rtx_ctx* c)
         if (c->pipe_stream[i]) (void)hipStreamDestroy(c->pipe_stream[i]);
         if (c->pipe_film[i]) (void)hipEventDestroy(c->pipe_film[i]);
         if (c->pipe_done[i]) (void)hipEventDestroy(c->pipe_done[i]);
+        if (c->aux_stream[i]) (void)hipStreamDestroy(c->aux_stream[i]);
+        if (c->ev_shade[i]) (void)hipEventDestroy(c->ev_shade[i]);
+        if (c->ev_shadow[i]) (void)hipEventDestroy(c->ev_shadow[i]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_tiles) (void)hipEventDestroy(c->ev_tiles);
@@ -258,9 +265,10 @@ int rtx_render_passes(rtx_ctx* c, int n)
     // own: late bounces hold few rays and a launch then lasts as long as its slowest ray, so
     // the passes fill each other's idle lanes. The film is still summed in pass order.
     const int lanes = std::max(1, std::min(n, c->pipeline));
+    if (c->spill_lanes < 2) { c->spill_lanes = 2; int rc = ensure_spill(c); if (rc) return rc; }
     if (lanes == 1) {
         for (int i = 0; i < n; i++) {
-            int rc = wavefront_render_pass(c, 0, c->stream, nullptr, nullptr);
+            int rc = wavefront_render_pass(c, 0, c->stream, nullptr, nullptr, c->overlap != 0);
             if (rc) return fail(rc, "render pass failed: %s", hipGetErrorString(hipGetLastError()));
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -268,7 +276,7 @@ int rtx_render_passes(rtx_ctx* c, int n)
     }
     for (int l = 1; l < lanes; l++)
         if (!c->wf[l]) { int rc = wavefront_alloc(c, l); if (rc) return fail(rc, "wavefront buffers: allocation failed"); }
-    if (c->spill_lanes < lanes) { c->spill_lanes = lanes; int rc = ensure_spill(c); if (rc) return rc; }
+    if (c->spill_lanes < 2 * lanes) { c->spill_lanes = 2 * lanes; int rc = ensure_spill(c); if (rc) return rc; }
     // lane 0 runs on the caller's stream itself, the others on streams of their own
     hipStream_t ls[kPipeline];
     for (int l = 0; l < lanes; l++) ls[l] = l == 0 ? c->stream : c->pipe_stream[l];
@@ -277,7 +285,7 @@ int rtx_render_passes(rtx_ctx* c, int n)
     const rtx_settings& st = c->settings;
     for (int i = 0; i < n; i++) {
         const int l = i % lanes;
-        int rc = wavefront_render_pass(c, l, ls[l], i > 0 ? c->pipe_film[(i - 1) % lanes] : nullptr, c->pipe_film[l]);
+        int rc = wavefront_render_pass(c, l, ls[l], i > 0 ? c->pipe_film[(i - 1) % lanes] : nullptr, c->pipe_film[l], false);
         if (rc) return fail(rc, "render pass failed: %s", hipGetErrorString(hipGetLastError()));
         if (c->spp == (int)st.init_spp && st.algorithm != RTX_AL_LIGHT_TRACE && st.shard_mode != 2) {
             // the adaptive sample targets were just computed on this lane: later passes read them
