@@ -3,11 +3,12 @@
 // renderMT() per progressive pass with the five console statistics, save the HDR when
 // totalSPP is reached. Flags of the reference: -scene, -outputFilename, -SPP
 // (RTBase/Main.cpp:104-115); added: -alg pt|lt|ir, -bounces N, -mis 0|1, -adaptive 0|1,
-// -seed N, -png file, -dumpFilm file (raw float sums), -dumpScene file, -orbit degrees (yaw the view first), -device N, -quiet 1.
+// -seed N, -png file, -dumpFilm file (raw float sums), -dumpScene file, -orbit degrees (yaw the view first), -batch N (passes per renderMT call), -device N, -quiet 1.
 //
 // -scene takes what the reference takes, a directory with scene.json + .gem meshes + textures
 // (GemScene.h), or an ".rtxs" dump (see SceneArrays.save in the Python package). -dumpScene file
 // writes the loaded scene as an .rtxs dump and exits without touching a GPU.
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <fstream>
@@ -142,7 +143,7 @@ static Scene* buildScene(const gem::SceneData& sd, int device)
 int main(int argc, char* argv[])
 {
     SETTINGS settings = createSettings();
-    std::string sceneName, filename = "render_GI.hdr", png, dump, dumpScene; int device = 0; bool quiet = false; float orbitDeg = 0.0f;
+    std::string sceneName, filename = "render_GI.hdr", png, dump, dumpScene; int device = 0, batch = 1; bool quiet = false; float orbitDeg = 0.0f;
     std::unordered_map<std::string, std::string> args;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -165,6 +166,7 @@ int main(int argc, char* argv[])
         else if (p.first == "-device") device = std::stoi(p.second);
         else if (p.first == "-quiet") quiet = std::stoi(p.second) != 0;
         else if (p.first == "-orbit") orbitDeg = std::stof(p.second);
+        else if (p.first == "-batch") batch = std::max(1, std::stoi(p.second));
         else std::cerr << "Warning: unknown flag '" << p.first << "'\n";
     }
     if (sceneName.empty()) { std::cerr << "usage: rt_headless -scene <scene directory | file.rtxs> [-outputFilename out.hdr] [-SPP n] ...\n"; return 2; }
@@ -185,7 +187,8 @@ int main(int argc, char* argv[])
         bool completed = false;
         while (!completed) {   // the body of the reference's frame loop, RTBase/Main.cpp:166-215
             timer.reset();
-            if (settings.useMultithreading) rt.renderMT(); else rt.render();
+            if (batch > 1) rt.renderMT(std::min<int>(batch, std::max<int>(1, (int)settings.totalSPP - rt.getSPP())));
+            else if (settings.useMultithreading) rt.renderMT(); else rt.render();
             float t = timer.dt();
             totalTime += t;
             float progress = rt.getSPP() * 100 / settings.totalSPP;
