@@ -62,6 +62,7 @@ struct Frame {                                   // Frame, RTBase/Core.h:519-555
 
 struct Shading {                                 // ShadingData, RTBase/Materials.h:11-31
     V3 x, wo, sNormal, gNormal; float tu, tv; Frame frame; const MaterialDev* mat; float t;
+    C3 alb;                                      // albedo->sample(tu, tv), fetched once per shading point
 };
 
 // SamplingDistributions, RTBase/Sampling.h:48-72
@@ -107,11 +108,7 @@ RTX_DI C3 tex_sample(const float* texels, int width, int height, float tu, float
     C3 s3 = ldc(texels + 3 * (y1 * width + x1));
     return (s0 * w0) + (s1 * w1) + (s2 * w2) + (s3 * w3);
 }
-RTX_DI C3 albedo(const DeviceScene& sc, const Shading& sd)
-{
-    const MaterialDev& m = *sd.mat;
-    return tex_sample(sc.texels + 3 * (size_t)m.tex_offset, m.tex_w, m.tex_h, sd.tu, sd.tv);
-}
+RTX_DI C3 albedo(const DeviceScene&, const Shading& sd) { return sd.alb; }
 
 // ShadingHelper, RTBase/Materials.h:44-112
 RTX_DI float fresnelDielectric(float cosTheta, float eta)
@@ -344,6 +341,7 @@ RTX_DI void shading_data(const DeviceScene& sc, const rtx_hit& h, V3 o, V3 d, Sh
     }
     sd.frame.fromVector(sd.sNormal);
     sd.t = h.t;
+    sd.alb = tex_sample(sc.texels + 3 * (size_t)sd.mat->tex_offset, sd.mat->tex_w, sd.mat->tex_h, sd.tu, sd.tv);
 }
 
 // ---- environment / background: RTBase/Lights.h:86-135, 138-305, 307-413 -----------------
