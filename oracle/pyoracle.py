@@ -273,3 +273,37 @@ class RefCore:
 
     def mt_stream(self, seed, n):
         o = np.empty(n, np.float32); self.lib.ref_mt_stream(seed, n, o.ctypes.data_as(_f)); return o
+
+
+class RefGem:
+    """The reference's own scene reader (RTBase/GEMLoader.h compiled as it is into
+    oracle/_ref/libref_gem.so): digest of a scene directory, see oracle/ref_gem.cpp."""
+
+    def __init__(self):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_gem.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = C.CDLL(path)
+        self.lib.ref_gem_digest.argtypes = [C.c_char_p, C.POINTER(C.c_uint64)]
+
+    def digest(self, directory):
+        out = (C.c_uint64 * 8)()
+        assert self.lib.ref_gem_digest(str(directory).encode(), out) == 0
+        return [int(v) for v in out]
+
+
+class RefStb:
+    """The reference's image decoder (RTBase/stb_image.h compiled as it is into
+    oracle/_ref/libref_stb.so): width, height, channels and pixel hash of a file, see oracle/ref_stb.cpp."""
+
+    def __init__(self):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_stb.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = C.CDLL(path)
+        self.lib.ref_stb_digest.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_uint64)]
+
+    def digest(self, path):
+        out = (C.c_uint64 * 4)()
+        rc = self.lib.ref_stb_digest(str(path).encode(), 1 if str(path).endswith(".hdr") else 0, out)
+        return None if rc else [int(v) for v in out]

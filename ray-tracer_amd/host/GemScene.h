@@ -375,6 +375,48 @@ inline void loadGemScene(const std::string& dir, SceneData& sd)
     else sd.background = Colour(0.0f, 0.0f, 0.0f);
 }
 
+// What this reader sees in a scene directory, condensed into eight numbers (FNV-1a hashes and
+// counts) for comparison with the same digest taken through the reference's own GEMLoader.h:
+// [0] scene properties, [1] hash of their (name, value) in iteration order, [2] instances,
+// [3] hash of (mesh file, 16 world floats, material properties), [4] vertices, [5] indices,
+// [6] hash of the 44-byte vertex records and the indices, [7] hash of the mesh-level properties.
+inline void digest(const std::string& dir, uint64_t out[8])
+{
+    struct Fnv {
+        uint64_t h = 1469598103934665603ull;
+        void bytes(const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } }
+        void str(const std::string& s) { uint32_t n = (uint32_t)s.size(); bytes(&n, 4); bytes(s.data(), s.size()); }
+    } props, inst, geo, mprops;
+    std::ifstream f(dir + "/scene.json");
+    if (!f) throw std::runtime_error("cannot open " + dir + "/scene.json");
+    std::stringstream buf; buf << f.rdbuf();
+    const std::string content = buf.str();
+    Json root = JsonReader(content).parse();
+    uint64_t nprops = 0, ninst = 0, nv = 0, ni = 0;
+    for (auto& item : root.obj) if (item.second.kind != Json::Arr) { props.str(item.first); props.str(item.second.text()); nprops++; }
+    for (auto& item : root.obj) {
+        if (item.second.kind != Json::Arr) continue;
+        for (const Json& in : item.second.arr) {
+            std::string meshFile; float world[16] = {0}; Properties mp;
+            for (auto& kv : in.obj) {
+                if (kv.first == "filename") meshFile = kv.second.text();
+                else if (kv.first == "world") { for (int i = 0; i < 16 && i < (int)kv.second.arr.size(); i++) world[i] = kv.second.arr[i].num; }
+                else mp.items.emplace_back(kv.first, kv.second.text());
+            }
+            inst.str(meshFile); inst.bytes(world, 64);
+            for (auto& p : mp.items) { inst.str(p.first); inst.str(p.second); }
+            ninst++;
+            for (const Mesh& m : readModel(dir + "/" + meshFile)) {
+                for (auto& p : m.material.items) { mprops.str(p.first); mprops.str(p.second); }
+                nv += m.vertices.size(); ni += m.indices.size();
+                if (!m.vertices.empty()) geo.bytes(m.vertices.data(), m.vertices.size() * sizeof(StaticVertex));
+                if (!m.indices.empty()) geo.bytes(m.indices.data(), m.indices.size() * 4);
+            }
+        }
+    }
+    out[0] = nprops; out[1] = props.h; out[2] = ninst; out[3] = inst.h; out[4] = nv; out[5] = ni; out[6] = geo.h; out[7] = mprops.h;
+}
+
 } // namespace gem
 
 // loadScene, RTBase/SceneLoader.h:337-389, with the reference's signature (plus the device to

@@ -3,7 +3,7 @@
 // renderMT() per progressive pass with the five console statistics, save the HDR when
 // totalSPP is reached. Flags of the reference: -scene, -outputFilename, -SPP
 // (RTBase/Main.cpp:104-115); added: -alg pt|lt|ir, -bounces N, -mis 0|1, -adaptive 0|1,
-// -seed N, -png file, -dumpFilm file (raw float sums), -dumpScene file, -orbit degrees (yaw the view first), -batch N (passes per renderMT call), -device N, -quiet 1.
+// -seed N, -png file, -dumpFilm file (raw float sums), -dumpScene file, -digestScene dir, -digestImage file, -orbit degrees (yaw the view first), -batch N (passes per renderMT call), -device N, -quiet 1.
 //
 // -scene takes what the reference takes, a directory with scene.json + .gem meshes + textures
 // (GemScene.h), or an ".rtxs" dump (see SceneArrays.save in the Python package). -dumpScene file
@@ -143,7 +143,7 @@ static Scene* buildScene(const gem::SceneData& sd, int device)
 int main(int argc, char* argv[])
 {
     SETTINGS settings = createSettings();
-    std::string sceneName, filename = "render_GI.hdr", png, dump, dumpScene; int device = 0, batch = 1; bool quiet = false; float orbitDeg = 0.0f;
+    std::string sceneName, filename = "render_GI.hdr", png, dump, dumpScene, digestDir, digestImage; int device = 0, batch = 1; bool quiet = false; float orbitDeg = 0.0f;
     std::unordered_map<std::string, std::string> args;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -163,11 +163,27 @@ int main(int argc, char* argv[])
         else if (p.first == "-png") png = p.second;
         else if (p.first == "-dumpFilm") dump = p.second;
         else if (p.first == "-dumpScene") dumpScene = p.second;
+        else if (p.first == "-digestScene") digestDir = p.second;
+        else if (p.first == "-digestImage") digestImage = p.second;
         else if (p.first == "-device") device = std::stoi(p.second);
         else if (p.first == "-quiet") quiet = std::stoi(p.second) != 0;
         else if (p.first == "-orbit") orbitDeg = std::stof(p.second);
         else if (p.first == "-batch") batch = std::max(1, std::stoi(p.second));
         else std::cerr << "Warning: unknown flag '" << p.first << "'\n";
+    }
+    if (!digestImage.empty()) {   // width, height, channels and FNV-1a hash of the decoded pixels of one image file
+        gem::Image img; const bool hdr = digestImage.find(".hdr") != std::string::npos;
+        if (!(hdr ? gem::readHdr(digestImage, img) : gem::readPng(digestImage, img))) { std::cerr << "error: cannot decode " << digestImage << std::endl; return 1; }
+        uint64_t h = 1469598103934665603ull;
+        const unsigned char* b = hdr ? (const unsigned char*)img.f.data() : img.u8.data();
+        const size_t nb = hdr ? img.f.size() * sizeof(float) : img.u8.size();
+        for (size_t i = 0; i < nb; i++) { h ^= b[i]; h *= 1099511628211ull; }
+        std::cout << img.width << " " << img.height << " " << img.channels << " " << h << "\n";
+        return 0;
+    }
+    if (!digestDir.empty()) {   // what the scene-directory reader sees, as eight numbers (see gem::digest); no GPU involved
+        try { uint64_t d[8]; gem::digest(digestDir, d); for (int i = 0; i < 8; i++) std::cout << d[i] << (i < 7 ? " " : "\n"); return 0; }
+        catch (const std::exception& e) { std::cerr << "error: " << e.what() << std::endl; return 1; }
     }
     if (sceneName.empty()) { std::cerr << "usage: rt_headless -scene <scene directory | file.rtxs> [-outputFilename out.hdr] [-SPP n] ...\n"; return 2; }
     try {
