@@ -177,3 +177,20 @@ def test_device_bvh_build_equals_host_build(pkg, lib, core, scenes, which):
     assert np.array_equal(t, ht), "topology / ranges differ"
     assert np.array_equal(i, hi), "index permutation differs"
     assert np.array_equal(b, hb), "bounds differ"
+
+
+def test_ragged_batch_sizes_of_the_dynamic_fetch(pkg, lib, core, orc, scenes):
+    """Ray counts around the chunk (64), counter (64 x 4 chunks) and grid boundaries: every ray
+    is traced exactly once whatever the remainder."""
+    sc = scenes.soup(5000, seed=31, size=0.05)
+    core.upload_scene(sc)
+    osc = orc.scene(sc)
+    big = _rand_rays(pkg, 1_000_003, 77)
+    want = osc.trace_closest(big, threads=8)
+    seg = np.random.RandomState(5).uniform(-1.1, 1.1, (300_007, 6)).astype(np.float32)
+    vis = osc.trace_visible(seg, threads=8)
+    for n in (1, 2, 63, 64, 65, 255, 256, 257, 4097, 16384 + 1, 262_144 + 63, 1_000_003):
+        _assert_hits_equal(core.trace_closest(big[:n]), want[:n])
+    for n in (1, 63, 65, 257, 300_007):
+        assert np.array_equal(core.trace_visible(seg[:n]), vis[:n])
+    osc.close()
