@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--pt-spp", type=int, default=16, help="passes of the path-trace side measurement")
     ap.add_argument("--variants", default="", help="A/B: comma list of RTX_VARIANT values, interleaved rounds in one process")
     ap.add_argument("--ab-scene", default="soup", choices=["soup", "mixed"])
+    ap.add_argument("--ab-repeat", type=int, default=1, help="A/B: trace the ray set this many times in one launch (tail measurement)")
     ap.add_argument("--ab-count", type=int, default=0, help="A/B: keep only this many rays (random subset)")
     ap.add_argument("--ab-rays", default="primary", choices=["primary", "bounce"], help="bounce: random directions from the primary hit points")
     args = ap.parse_args()
@@ -114,6 +115,10 @@ def main():
         keep = torch.randperm(n, generator=g, device=dev)[:args.ab_count].sort().values
         rays = rays.view(n, RAY_BYTES)[keep].contiguous().view(-1)
         n = args.ab_count
+        hits = torch.empty(n * HIT_BYTES, dtype=torch.uint8, device=dev)
+    if args.variants and args.ab_repeat > 1:
+        rays = rays.view(n, RAY_BYTES).repeat(args.ab_repeat, 1).contiguous().view(-1)
+        n *= args.ab_repeat
         hits = torch.empty(n * HIT_BYTES, dtype=torch.uint8, device=dev)
     if args.variants:
         ab_variants(pkg, lib, scene, cam, args, rays, hits, n, torch, local_rank)

@@ -2,10 +2,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cfloat>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "context.h"
 #include "trace_kernels.h"
@@ -480,6 +482,18 @@ int rtx_count_closest_work(rtx_ctx* c, const rtx_ray* rays, size_t n, uint64_t* 
     unsigned long long h[5];
     HIP_TRY(hipMemcpyAsync(h, c->b_counters.p, 40, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (getenv("RTX_DEBUG_COUNTERS")) {
+        // distribution of the dependent steps of a ray (node visits + groups of four triangle tests): the slowest
+        // ray bounds how long a launch lasts after its queue has run dry
+        std::vector<rtx_hit> hh(n);
+        HIP_TRY(hipMemcpy(hh.data(), c->b_io_b.p, n * sizeof(rtx_hit), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> steps(n);
+        for (size_t i = 0; i < n; i++) steps[i] = hh[i].t < FLT_MAX || hh[i].alpha > 0 ? (uint32_t)hh[i].alpha + ((uint32_t)hh[i].beta + 3) / 4 : 0;
+        std::sort(steps.begin(), steps.end());
+        double sum = 0; for (uint32_t v : steps) sum += v;
+        fprintf(stderr, "[rtx] dependent steps per ray: mean %.1f, median %u, p90 %u, p99 %u, p99.9 %u, max %u\n", sum / (double)n, steps[n / 2], steps[n * 9 / 10],
+                steps[n * 99 / 100], steps[(size_t)(n * 0.999)], steps[n - 1]);
+    }
     if (getenv("RTX_DEBUG_COUNTERS"))
         fprintf(stderr, "[rtx] lane node visits %llu, lane tri tests %llu; wave inner trips %llu, wave tri trips %llu, wave outer trips %llu\n", h[0], h[1], h[2], h[3], h[4]);
     *nodes = h[0]; *tris = h[1];

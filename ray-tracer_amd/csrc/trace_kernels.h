@@ -68,6 +68,8 @@ struct ClosestPolicy {
         o[0] = r.o[0]; o[1] = r.o[1]; o[2] = r.o[2]; d[0] = r.d[0]; d[1] = r.d[1]; d[2] = r.d[2]; maxT = 0.0f;
     }
     __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool) const { hits[index(k)] = make_hit(sc, best); }
+    // instrumented runs only: the ray's node visits and triangle tests replace two barycentrics of the (scratch) hit record
+    __device__ __forceinline__ void note(uint32_t k, uint32_t nodes, uint32_t tris) const { hits[index(k)].alpha = (float)nodes; hits[index(k)].beta = (float)tris; }
 };
 
 // rays[queue ? queue[i] : i] for i < (n_dev ? *n_dev : n_host); *work_counter must be 0 at launch

@@ -45,7 +45,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
 {
     const uint32_t lane = threadIdx.x & 63u;
     constexpr uint32_t kNone = 0xFFFFFFFFu;
-    TravCount cnt{0, 0};
+    TravCount cnt{0, 0}, mark{0, 0};   // mark: the counters when the lane's current ray started (COUNT only)
     uint32_t wave_iters[3] = {0, 0, 0};   // COUNT only: inner-loop, triangle-loop and outer-loop trips of this lane
     uint32_t cur = kDone, item = kNone;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, bound = FLT_MAX, maxT = 0;
@@ -62,7 +62,11 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
     bool exhausted = false;
     for (;;) {
         // retire finished rays
-        if (cur == kDone && item != kNone) { pol.retire(item, best, true); item = kNone; }
+        if (cur == kDone && item != kNone) {
+            pol.retire(item, best, true);
+            if constexpr (COUNT) pol.note(item, cnt.nodes - mark.nodes, cnt.tris - mark.tris);
+            item = kNone;
+        }
         unsigned long long m = __ballot(cur == kDone);
         uint32_t n_idle = (uint32_t)__popcll(m);
         while (!exhausted && n_idle >= (uint32_t)REFILL) {
@@ -97,7 +101,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
                 // root box first (Geometry.h:509 / :571)
                 if (slab_reference(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ox, oy, oz, ix, iy, iz)) {
                     const bool finite = (fabsf(ix) <= FLT_MAX) && (fabsf(iy) <= FLT_MAX) && (fabsf(iz) <= FLT_MAX);
-                    if (finite) { cur = 0; item = k; }
+                    if (finite) { cur = 0; item = k; mark = cnt; }
                     else { traverse_exact<ANY, BLOCK, LDS_N>(sc, stk, ox, oy, oz, dx, dy, dz, ix, iy, iz, maxT, best); pol.retire(k, best, true); }
                 } else pol.retire(k, best, false);
             }
