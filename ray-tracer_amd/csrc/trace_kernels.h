@@ -11,6 +11,7 @@ constexpr float kEpsilon = 0.001f;    // EPSILON, RTBase/Geometry.h:54
 constexpr int kRefill = 20;           // idle lanes that trigger a fetch of new rays
 constexpr int kTriUnroll = 4;         // leaf triangles whose loads are issued together
 constexpr int kLeafLanes = 28;        // the wave stops descending and tests triangles once this many lanes hold a leaf
+constexpr int kShare = 1;             // idle lanes share the pending subtrees of busy ones once the work counters are dry
 
 __device__ __forceinline__ uint32_t global_thread() { return blockIdx.x * kBlock + threadIdx.x; }
 
@@ -81,18 +82,21 @@ __global__ __launch_bounds__(kBlock) void k_closest(DeviceScene sc, const rtx_ra
     __shared__ unsigned long long lds[kBlock * kLdsStack];
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     ClosestPolicy pol{sc, rays, queue, hits};
-    traverse_dyn<ClosestPolicy, false, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes>(sc, stk, n_dev ? *n_dev : n_host, work_counter, pol, counters);
+    // the instrumented pass counts what one lane per ray visits, without helpers' speculative work
+    __shared__ TailShare<kBlock> ts;
+    traverse_dyn<ClosestPolicy, false, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, COUNT ? 0 : kShare>(sc, stk, n_dev ? *n_dev : n_host, work_counter, pol, counters, &ts);
 }
 
 // Schedules under test (A/B harness only)
-template <int REFILL, int UNROLL, int SCHED, int LDS_N, int WAVES>
+template <int REFILL, int UNROLL, int SCHED, int LDS_N, int WAVES, int SHARE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_closest_ab(DeviceScene sc, const rtx_ray* __restrict__ rays, uint32_t n, rtx_hit* __restrict__ hits,
                                                        uint2* spill, uint32_t spill_stride, uint32_t* work_counter)
 {
     __shared__ unsigned long long lds[kBlock * LDS_N];
     LaneStack<kBlock, LDS_N> stk; stk.init(lds, spill, spill_stride);
     ClosestPolicy pol{sc, rays, nullptr, hits};
-    traverse_dyn<ClosestPolicy, false, false, REFILL, kBlock, LDS_N, UNROLL, SCHED>(sc, stk, n, work_counter, pol, nullptr);
+    __shared__ TailShare<kBlock> ts;
+    traverse_dyn<ClosestPolicy, false, false, REFILL, kBlock, LDS_N, UNROLL, SCHED, SHARE>(sc, stk, n, work_counter, pol, nullptr, &ts);
 }
 
 // ---- visibility: Scene::visible, RTBase/Scene.h:170-178 -> traverseVisible, Geometry.h:568-610 ----
@@ -109,7 +113,8 @@ __global__ __launch_bounds__(kBlock) void k_visible(DeviceScene sc, const float*
     __shared__ unsigned long long lds[kBlock * kLdsStack];
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     VisiblePolicy pol{p1p2, visible};
-    traverse_dyn<VisiblePolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes>(sc, stk, n, work_counter, pol, nullptr);
+    __shared__ TailShare<kBlock> ts;
+    traverse_dyn<VisiblePolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, n, work_counter, pol, nullptr, &ts);
 }
 
 // One segment, inside a kernel that loops over segments per lane (the VPL gather)

@@ -39,12 +39,48 @@ __device__ __forceinline__ uint32_t work_chunk(uint32_t j, uint32_t seg)
     return (((j >> 2) * (uint32_t)kWorkSegments + (seg & 7u) * 8u + (seg >> 3)) << 2) + (j & 3u);
 }
 
-template <class Policy, bool ANY, bool COUNT, int REFILL, int BLOCK, int LDS_N, int TRI_UNROLL, int SCHED>
+// Tail sharing. When the work counters have run dry, the launch lasts as long as the longest
+// ray still in flight (a few rays walk ten times the mean number of nodes), with most lanes
+// of their waves idle. From then on an idle lane takes pending subtrees off the traversal
+// stack of a busy lane of its wave, oldest (largest) first, and walks them for that lane's
+// ray. Per-lane mailboxes in LDS collect what the helpers find: `key` is the best candidate of
+// the lane's ray so far, packed so that an unsigned minimum is the reference's rule (smaller t,
+// then earlier triangle); `pending` counts helpers still at work. The ray retires when its own
+// lane and all helpers are done. Candidates and arithmetic are unchanged, the minimum is
+// order-independent, so results are the same as without sharing.
+template <int BLOCK>
+struct TailShare {
+    unsigned long long key[BLOCK];
+    uint32_t pending[BLOCK];
+};
+
+// mailbox words are written by other lanes of the wave: read them as atomics so that the load is neither hoisted nor merged
+template <class T> __device__ __forceinline__ T lds_read(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+__device__ __forceinline__ unsigned long long pack_hit(const HitRec& b) { return ((unsigned long long)__float_as_uint(b.t) << 32) | b.pos; }
+
+// position of the n-th set bit of m (n < popcount(m))
+__device__ __forceinline__ uint32_t nth_set_bit(unsigned long long m, uint32_t n)
+{
+    uint32_t pos = 0;
+#pragma unroll
+    for (uint32_t w = 32; w > 0; w >>= 1) {
+        const uint32_t c = (uint32_t)__popcll((m >> pos) & ((1ull << w) - 1ull));
+        if (n >= c) { n -= c; pos += w; }
+    }
+    return pos;
+}
+
+template <class Policy, bool ANY, bool COUNT, int REFILL, int BLOCK, int LDS_N, int TRI_UNROLL, int SCHED, int SHARE = 0>
 __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BLOCK, LDS_N>& stk, uint32_t n, uint32_t* work,
-                                             Policy& pol, unsigned long long* counters)
+                                             Policy& pol, unsigned long long* counters, TailShare<BLOCK>* ts = nullptr)
 {
     const uint32_t lane = threadIdx.x & 63u;
     constexpr uint32_t kNone = 0xFFFFFFFFu;
+    // item values from kHelper up (except kNone): the lane helps the ray of lane (item & 63) of its wave
+    constexpr uint32_t kHelper = 0xFFFFFF00u;
+    const uint32_t wave0 = threadIdx.x & ~63u;
+    bool tail = SHARE == 2;   // SHARE: the mailboxes are set up (SHARE == 2: from the start, idle lanes help whenever there are any)
     TravCount cnt{0, 0}, mark{0, 0};   // mark: the counters when the lane's current ray started (COUNT only)
     uint32_t wave_iters[3] = {0, 0, 0};   // COUNT only: inner-loop, triangle-loop and outer-loop trips of this lane
     uint32_t cur = kDone, item = kNone;
@@ -61,13 +97,39 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
     uint32_t seg = blockIdx.x % (uint32_t)kWorkSegments, loc_next = 0, loc_end = 0;
     bool exhausted = false;
     for (;;) {
-        // retire finished rays
-        if (cur == kDone && item != kNone) {
-            pol.retire(item, best, true);
-            if constexpr (COUNT) pol.note(item, cnt.nodes - mark.nodes, cnt.tris - mark.tris);
-            item = kNone;
+        if constexpr (SHARE) {
+            if (tail && item != kNone) {
+                const uint32_t own = wave0 + (item >= kHelper ? (item & 63u) : lane);
+                if (item >= kHelper && cur == kDone) {
+                    // a helper hands in what it found
+                    if (best.pos != kNone) atomicMin(&ts->key[own], pack_hit(best));
+                    atomicSub(&ts->pending[own], 1u);
+                    item = kNone;
+                } else if (ANY && cur != kDone && (uint32_t)lds_read(&ts->key[own]) != kNone) {
+                    cur = kDone; stk.sp = stk.base;     // somebody found an occluder for this ray
+                }
+            }
         }
-        unsigned long long m = __ballot(cur == kDone);
+        // retire finished rays
+        if (cur == kDone && item != kNone && (!SHARE || item < kHelper)) {
+            bool ready = true;
+            if constexpr (SHARE) {
+                if (tail) {
+                    ready = lds_read(&ts->pending[threadIdx.x]) == 0u;
+                    const unsigned long long kk = lds_read(&ts->key[threadIdx.x]);
+                    if (ready && kk < pack_hit(best)) {
+                        best.pos = (uint32_t)kk; best.t = __uint_as_float((uint32_t)(kk >> 32));
+                        if (!ANY) { float t; tri_test(sc.tris[best.pos], ox, oy, oz, dx, dy, dz, t, best.u, best.v); }
+                    }
+                }
+            }
+            if (ready) {
+                pol.retire(item, best, true);
+                if constexpr (COUNT) pol.note(item, cnt.nodes - mark.nodes, cnt.tris - mark.tris);
+                item = kNone;
+            }
+        }
+        unsigned long long m = __ballot(cur == kDone && item == kNone);
         uint32_t n_idle = (uint32_t)__popcll(m);
         while (!exhausted && n_idle >= (uint32_t)REFILL) {
             if (loc_next == loc_end) {
@@ -90,26 +152,65 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
             }
             const uint32_t take = min(n_idle, loc_end - loc_next);
             const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (cur == kDone && rank < take) {
+            if (cur == kDone && item == kNone && rank < take) {
                 const uint32_t k = loc_next + rank;
                 float o[3], d[3];
                 pol.fetch(k, o, d, maxT);
                 ox = o[0]; oy = o[1]; oz = o[2]; dx = d[0]; dy = d[1]; dz = d[2];
                 ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;                                    // Ray::init, Geometry.h:25
-                best.t = FLT_MAX; best.u = best.v = 0; best.pos = kNone; stk.sp = 0;
+                best.t = FLT_MAX; best.u = best.v = 0; best.pos = kNone; stk.sp = 0; stk.base = 0;
                 bound = ANY ? (maxT + (fabsf(maxT) * kCullRel + kCullAbs)) : FLT_MAX;
                 // root box first (Geometry.h:509 / :571)
                 if (slab_reference(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ox, oy, oz, ix, iy, iz)) {
                     const bool finite = (fabsf(ix) <= FLT_MAX) && (fabsf(iy) <= FLT_MAX) && (fabsf(iz) <= FLT_MAX);
-                    if (finite) { cur = 0; item = k; mark = cnt; }
+                    if (finite) {
+                        cur = 0; item = k; mark = cnt;
+                        if constexpr (SHARE == 2) { ts->key[threadIdx.x] = pack_hit(best); ts->pending[threadIdx.x] = 0u; }
+                    }
                     else { traverse_exact<ANY, BLOCK, LDS_N>(sc, stk, ox, oy, oz, dx, dy, dz, ix, iy, iz, maxT, best); pol.retire(k, best, true); }
                 } else pol.retire(k, best, false);
             }
             loc_next += take;
-            m = __ballot(cur == kDone);
+            m = __ballot(cur == kDone && item == kNone);
             n_idle = (uint32_t)__popcll(m);
         }
-        if (exhausted && __all(cur == kDone)) break;
+        if constexpr (SHARE) {
+            if (exhausted || SHARE == 2) {
+                if (!tail) { ts->key[threadIdx.x] = pack_hit(best); ts->pending[threadIdx.x] = 0u; tail = true; }
+                const unsigned long long freeM = __ballot(cur == kDone && item == kNone);
+                const unsigned long long donM = __ballot(cur != kDone && stk.sp > stk.base);
+                if (freeM != 0ull && donM != 0ull) {
+                    const uint32_t nF = (uint32_t)__popcll(freeM), nD = (uint32_t)__popcll(donM);
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    // free lane r helps donor r % nD and takes that donor's (r / nD)-th oldest entry
+                    const uint32_t r = (uint32_t)__popcll(freeM & below);
+                    const uint32_t dl = nth_set_bit(donM, r % nD), q = r / nD;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the donors' stack stores have landed
+                    const int d_sp = __shfl(stk.sp, (int)dl, 64), d_base = __shfl(stk.base, (int)dl, 64);
+                    const uint32_t d_item = (uint32_t)__shfl((int)item, (int)dl, 64);
+                    const float sox = __shfl(ox, (int)dl, 64), soy = __shfl(oy, (int)dl, 64), soz = __shfl(oz, (int)dl, 64);
+                    const float sdx = __shfl(dx, (int)dl, 64), sdy = __shfl(dy, (int)dl, 64), sdz = __shfl(dz, (int)dl, 64);
+                    const float six = __shfl(ix, (int)dl, 64), siy = __shfl(iy, (int)dl, 64), siz = __shfl(iz, (int)dl, 64);
+                    const float smax = __shfl(maxT, (int)dl, 64), sbound = __shfl(bound, (int)dl, 64);
+                    const bool is_free = (cur == kDone && item == kNone);
+                    if (cur != kDone && stk.sp > stk.base) {
+                        const uint32_t rd = (uint32_t)__popcll(donM & below);
+                        const uint32_t offered = rd < nF ? (nF - rd + nD - 1u) / nD : 0u;
+                        stk.base += (int)min(offered, (uint32_t)(stk.sp - stk.base));
+                    } else if (is_free && d_base + (int)q < d_sp) {
+                        const uint2 e = stk.peek_other(d_base + (int)q, (int)dl - (int)lane);
+                        ox = sox; oy = soy; oz = soz; dx = sdx; dy = sdy; dz = sdz; ix = six; iy = siy; iz = siz; maxT = smax; bound = sbound;
+                        best.t = FLT_MAX; best.u = best.v = 0; best.pos = kNone; stk.sp = 0; stk.base = 0;
+                        const uint32_t own = d_item >= kHelper ? (d_item & 63u) : dl;
+                        item = kHelper | own;
+                        atomicAdd(&ts->pending[wave0 + own], 1u);
+                        cur = (__uint_as_float(e.y) > bound) ? kDone : e.x;
+                        if constexpr (COUNT) mark = cnt;
+                    }
+                }
+            }
+        }
+        if (exhausted && __all(cur == kDone && item == kNone)) break;
         if (COUNT) wave_iters[2]++;
         // every lane descends until it holds a leaf
         if (SCHED == 0) {
@@ -146,9 +247,23 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
                 }
                 if (ANY && occluded) break;
             }
-            if (ANY && occluded) cur = kDone;
-            else {
-                if (!ANY) bound = best.t + (fabsf(best.t) * kCullRel + kCullAbs);
+            if (ANY && occluded) {
+                cur = kDone;
+                if constexpr (SHARE) { if (tail) { atomicMin(&ts->key[wave0 + (item >= kHelper ? (item & 63u) : lane)], pack_hit(best)); stk.sp = stk.base; } }
+            } else {
+                if (!ANY) {
+                    float bt = best.t;
+                    if constexpr (SHARE) {
+                        if (tail) {
+                            // publish this lane's best and prune against the best anyone has found for the ray
+                            const uint32_t own = wave0 + (item >= kHelper ? (item & 63u) : lane);
+                            const unsigned long long mine = pack_hit(best);
+                            const unsigned long long old = best.pos != kNone ? atomicMin(&ts->key[own], mine) : lds_read(&ts->key[own]);
+                            bt = __uint_as_float((uint32_t)((old < mine ? old : mine) >> 32));
+                        }
+                    }
+                    bound = bt + (fabsf(bt) * kCullRel + kCullAbs);
+                }
                 cur = pop_next(stk, bound);
             }
         }

@@ -326,7 +326,8 @@ __global__ __launch_bounds__(kBlock) void k_shadow_accumulate(WfPtrs w, DeviceSc
     __shared__ unsigned long long lds[kBlock * kLdsStack];
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     ShadowAccumulatePolicy pol{w};
-    traverse_dyn<ShadowAccumulatePolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, nullptr);
+    __shared__ TailShare<kBlock> ts;
+    traverse_dyn<ShadowAccumulatePolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, nullptr, &ts);
 }
 
 // film->splat(px, py, col) for every sample of the pass, Renderer.h:745
@@ -505,7 +506,8 @@ __global__ __launch_bounds__(kBlock) void k_lt_splat(WfPtrs w, DeviceScene sc, u
     __shared__ unsigned long long lds[kBlock * kLdsStack];
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     SplatPolicy pol{w, filter};
-    traverse_dyn<SplatPolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, nullptr);
+    __shared__ TailShare<kBlock> ts;
+    traverse_dyn<SplatPolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, nullptr, &ts);
 }
 
 // ---- instant radiosity: RTBase/Renderer.h:124-302 -------------------------------------------
