@@ -31,7 +31,8 @@ int fail(int code, const char* fmt, ...)
 template <class T>
 int upload(DevBuf& b, const std::vector<T>& v, hipStream_t s)
 {
-    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    // slack behind the payload: kernels may load (never use) up to three triangle records past the end
+    size_t bytes = v.size() * sizeof(T) + 128;
     HIP_TRY(b.ensure(bytes));
     if (!v.empty()) HIP_TRY(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
     return RTX_OK;

@@ -48,6 +48,8 @@ __device__ __forceinline__ uint32_t work_chunk(uint32_t j, uint32_t seg)
 // then earlier triangle); `pending` counts helpers still at work. The ray retires when its own
 // lane and all helpers are done. Candidates and arithmetic are unchanged, the minimum is
 // order-independent, so results are the same as without sharing.
+struct __attribute__((packed, aligned(4))) TriQuad { float f[36]; };
+
 template <int BLOCK>
 struct TailShare {
     unsigned long long key[BLOCK];
@@ -231,8 +233,18 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
             bool occluded = false;
             for (uint32_t k = 0; k < nt; k += TRI_UNROLL) {
                 TriIsect T[TRI_UNROLL];
+                if constexpr (TRI_UNROLL == 4) {
+                    // four consecutive 36-byte records are 144 bytes = nine 16-byte loads instead of twelve
+                    // (4-byte aligned; records past the leaf's end are loaded but not tested, the array is padded)
+                    const TriQuad Q = *(const TriQuad*)(sc.tris + first + k);
 #pragma unroll
-                for (int j = 0; j < TRI_UNROLL; j++) T[j] = sc.tris[first + min(k + (uint32_t)j, nt - 1u)];
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int q = 0; q < 3; q++) { T[j].e1[q] = Q.f[j * 9 + q]; T[j].e2[q] = Q.f[j * 9 + 3 + q]; T[j].v2[q] = Q.f[j * 9 + 6 + q]; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TRI_UNROLL; j++) T[j] = sc.tris[first + min(k + (uint32_t)j, nt - 1u)];
+                }
                 if (COUNT) wave_iters[1]++;
 #pragma unroll
                 for (int j = 0; j < TRI_UNROLL; j++) {
