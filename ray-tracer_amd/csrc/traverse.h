@@ -275,18 +275,15 @@ __device__ __forceinline__ uint32_t step_inner(const DeviceScene& sc, LaneStack<
     // without short-circuit below) so that their load stays with the other six instead of becoming
     // a dependent load behind the first box test
     const bool valid[4] = {ref[0] != kEmptySlot, ref[1] != kEmptySlot, ref[2] != kEmptySlot, ref[3] != kEmptySlot};
-    // (plane - origin) * reciprocal for two children at a time: CDNA's packed fp32 add / mul take the
-    // register pairs as the loads deliver them and round each half exactly like the scalar forms
-    typedef float Pair __attribute__((ext_vector_type(2)));
-    const Pair O[3] = {{ox, ox}, {oy, oy}, {oz, oz}}, I[3] = {{ix, ix}, {iy, iy}, {iz, iz}};
+    // scalar subtract / multiply on purpose: the packed two-float forms cost more issue time than two scalar
+    // instructions on this hardware (the library is also built without SLP vectorisation for that reason)
+    const float O[3] = {ox, oy, oz}, I[3] = {ix, iy, iz};
     const float4 lo4[3] = {lox, loy, loz}, hi4[3] = {hix, hiy, hiz};
     float t0[3][4], t1[3][4];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        const Pair l01 = {lo4[a].x, lo4[a].y}, l23 = {lo4[a].z, lo4[a].w}, h01 = {hi4[a].x, hi4[a].y}, h23 = {hi4[a].z, hi4[a].w};
-        const Pair a01 = (l01 - O[a]) * I[a], a23 = (l23 - O[a]) * I[a], b01 = (h01 - O[a]) * I[a], b23 = (h23 - O[a]) * I[a];
-        t0[a][0] = a01.x; t0[a][1] = a01.y; t0[a][2] = a23.x; t0[a][3] = a23.y;
-        t1[a][0] = b01.x; t1[a][1] = b01.y; t1[a][2] = b23.x; t1[a][3] = b23.y;
+        t0[a][0] = (lo4[a].x - O[a]) * I[a]; t0[a][1] = (lo4[a].y - O[a]) * I[a]; t0[a][2] = (lo4[a].z - O[a]) * I[a]; t0[a][3] = (lo4[a].w - O[a]) * I[a];
+        t1[a][0] = (hi4[a].x - O[a]) * I[a]; t1[a][1] = (hi4[a].y - O[a]) * I[a]; t1[a][2] = (hi4[a].z - O[a]) * I[a]; t1[a][3] = (hi4[a].w - O[a]) * I[a];
     }
     float key[4]; uint32_t kref[4];
 #pragma unroll
