@@ -103,12 +103,11 @@ struct LaneStack {
     GlobalWord64* spill;   // this lane's first global entry; consecutive entries are `stride` apart
     uint32_t stride;
     int sp;
-    int base;              // entries below `base` have been handed to other lanes (tail sharing); 0 otherwise
     __device__ __forceinline__ void init(unsigned long long* lds_array, uint2* spill_slab, uint32_t spill_stride)
     {
         lds = (LdsWord64*)lds_array;
         spill = (GlobalWord64*)(spill_slab + blockIdx.x * (uint32_t)BLOCK + threadIdx.x);
-        stride = spill_stride; sp = 0; base = 0;
+        stride = spill_stride; sp = 0;
     }
     // entry i of the lane `delta` lanes away in the same wave
     __device__ __forceinline__ uint2 peek_other(int i, int delta) const
@@ -254,7 +253,7 @@ template <int BLOCK, int LDS_N>
 __device__ __forceinline__ uint32_t pop_next(LaneStack<BLOCK, LDS_N>& stk, float bound)
 {
     for (;;) {
-        if (stk.sp == stk.base) return kDone;
+        if (stk.sp == 0) return kDone;
         uint2 e = stk.pop();
         if (!(__uint_as_float(e.y) > bound)) return e.x;
     }

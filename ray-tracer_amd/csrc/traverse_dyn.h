@@ -42,8 +42,9 @@ __device__ __forceinline__ uint32_t work_chunk(uint32_t j, uint32_t seg)
 // Tail sharing. When the work counters have run dry, the launch lasts as long as the longest
 // ray still in flight (a few rays walk ten times the mean number of nodes), with most lanes
 // of their waves idle. From then on an idle lane takes pending subtrees off the traversal
-// stack of a busy lane of its wave, oldest (largest) first, and walks them for that lane's
-// ray. Per-lane mailboxes in LDS collect what the helpers find: `key` is the best candidate of
+// stack of a busy lane of its wave, newest (nearest) first — the entries that lane would visit
+// next itself, so the helpers work on the ray's likely critical path and a hit they find prunes
+// the far entries — and walks them for that lane's ray. Per-lane mailboxes in LDS collect what the helpers find: `key` is the best candidate of
 // the lane's ray so far, packed so that an unsigned minimum is the reference's rule (smaller t,
 // then earlier triangle); `pending` counts helpers still at work. The ray retires when its own
 // lane and all helpers are done. Candidates and arithmetic are unchanged, the minimum is
@@ -82,7 +83,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
     // item values from kHelper up (except kNone): the lane helps the ray of lane (item & 63) of its wave
     constexpr uint32_t kHelper = 0xFFFFFF00u;
     const uint32_t wave0 = threadIdx.x & ~63u;
-    bool tail = SHARE == 2;   // SHARE: the mailboxes are set up (SHARE == 2: from the start, idle lanes help whenever there are any)
+    bool tail = false;   // SHARE: the mailboxes are set up
     TravCount cnt{0, 0}, mark{0, 0};   // mark: the counters when the lane's current ray started (COUNT only)
     uint32_t wave_iters[3] = {0, 0, 0};   // COUNT only: inner-loop, triangle-loop and outer-loop trips of this lane
     uint32_t cur = kDone, item = kNone;
@@ -108,7 +109,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
                     atomicSub(&ts->pending[own], 1u);
                     item = kNone;
                 } else if (ANY && cur != kDone && (uint32_t)lds_read(&ts->key[own]) != kNone) {
-                    cur = kDone; stk.sp = stk.base;     // somebody found an occluder for this ray
+                    cur = kDone; stk.sp = 0;     // somebody found an occluder for this ray
                 }
             }
         }
@@ -160,14 +161,13 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
                 pol.fetch(k, o, d, maxT);
                 ox = o[0]; oy = o[1]; oz = o[2]; dx = d[0]; dy = d[1]; dz = d[2];
                 ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;                                    // Ray::init, Geometry.h:25
-                best.t = FLT_MAX; best.u = best.v = 0; best.pos = kNone; stk.sp = 0; stk.base = 0;
+                best.t = FLT_MAX; best.u = best.v = 0; best.pos = kNone; stk.sp = 0;
                 bound = ANY ? (maxT + (fabsf(maxT) * kCullRel + kCullAbs)) : FLT_MAX;
                 // root box first (Geometry.h:509 / :571)
                 if (slab_reference(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ox, oy, oz, ix, iy, iz)) {
                     const bool finite = (fabsf(ix) <= FLT_MAX) && (fabsf(iy) <= FLT_MAX) && (fabsf(iz) <= FLT_MAX);
                     if (finite) {
                         cur = 0; item = k; mark = cnt;
-                        if constexpr (SHARE == 2) { ts->key[threadIdx.x] = pack_hit(best); ts->pending[threadIdx.x] = 0u; }
                     }
                     else { traverse_exact<ANY, BLOCK, LDS_N>(sc, stk, ox, oy, oz, dx, dy, dz, ix, iy, iz, maxT, best); pol.retire(k, best, true); }
                 } else pol.retire(k, best, false);
@@ -177,32 +177,32 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
             n_idle = (uint32_t)__popcll(m);
         }
         if constexpr (SHARE) {
-            if (exhausted || SHARE == 2) {
+            if (exhausted) {
                 if (!tail) { ts->key[threadIdx.x] = pack_hit(best); ts->pending[threadIdx.x] = 0u; tail = true; }
                 const unsigned long long freeM = __ballot(cur == kDone && item == kNone);
-                const unsigned long long donM = __ballot(cur != kDone && stk.sp > stk.base);
+                const unsigned long long donM = __ballot(cur != kDone && stk.sp > 0);
                 if (freeM != 0ull && donM != 0ull) {
                     const uint32_t nF = (uint32_t)__popcll(freeM), nD = (uint32_t)__popcll(donM);
                     const unsigned long long below = (1ull << lane) - 1ull;
-                    // free lane r helps donor r % nD and takes that donor's (r / nD)-th oldest entry
+                    // free lane r helps donor r % nD and takes that donor's (r / nD)-th newest entry
                     const uint32_t r = (uint32_t)__popcll(freeM & below);
                     const uint32_t dl = nth_set_bit(donM, r % nD), q = r / nD;
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the donors' stack stores have landed
-                    const int d_sp = __shfl(stk.sp, (int)dl, 64), d_base = __shfl(stk.base, (int)dl, 64);
+                    const int d_sp = __shfl(stk.sp, (int)dl, 64);
                     const uint32_t d_item = (uint32_t)__shfl((int)item, (int)dl, 64);
                     const float sox = __shfl(ox, (int)dl, 64), soy = __shfl(oy, (int)dl, 64), soz = __shfl(oz, (int)dl, 64);
                     const float sdx = __shfl(dx, (int)dl, 64), sdy = __shfl(dy, (int)dl, 64), sdz = __shfl(dz, (int)dl, 64);
                     const float six = __shfl(ix, (int)dl, 64), siy = __shfl(iy, (int)dl, 64), siz = __shfl(iz, (int)dl, 64);
                     const float smax = __shfl(maxT, (int)dl, 64), sbound = __shfl(bound, (int)dl, 64);
                     const bool is_free = (cur == kDone && item == kNone);
-                    if (cur != kDone && stk.sp > stk.base) {
+                    if (cur != kDone && stk.sp > 0) {
                         const uint32_t rd = (uint32_t)__popcll(donM & below);
                         const uint32_t offered = rd < nF ? (nF - rd + nD - 1u) / nD : 0u;
-                        stk.base += (int)min(offered, (uint32_t)(stk.sp - stk.base));
-                    } else if (is_free && d_base + (int)q < d_sp) {
-                        const uint2 e = stk.peek_other(d_base + (int)q, (int)dl - (int)lane);
+                        stk.sp -= (int)min(offered, (uint32_t)stk.sp);
+                    } else if (is_free && (int)q < d_sp) {
+                        const uint2 e = stk.peek_other(d_sp - 1 - (int)q, (int)dl - (int)lane);
                         ox = sox; oy = soy; oz = soz; dx = sdx; dy = sdy; dz = sdz; ix = six; iy = siy; iz = siz; maxT = smax; bound = sbound;
-                        best.t = FLT_MAX; best.u = best.v = 0; best.pos = kNone; stk.sp = 0; stk.base = 0;
+                        best.t = FLT_MAX; best.u = best.v = 0; best.pos = kNone; stk.sp = 0;
                         const uint32_t own = d_item >= kHelper ? (d_item & 63u) : dl;
                         item = kHelper | own;
                         atomicAdd(&ts->pending[wave0 + own], 1u);
@@ -261,7 +261,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
             }
             if (ANY && occluded) {
                 cur = kDone;
-                if constexpr (SHARE) { if (tail) { atomicMin(&ts->key[wave0 + (item >= kHelper ? (item & 63u) : lane)], pack_hit(best)); stk.sp = stk.base; } }
+                if constexpr (SHARE) { if (tail) { atomicMin(&ts->key[wave0 + (item >= kHelper ? (item & 63u) : lane)], pack_hit(best)); stk.sp = 0; } }
             } else {
                 if (!ANY) {
                     float bt = best.t;
