@@ -185,6 +185,8 @@ std::string prepare_scene(const rtx_scene_desc& d, HostScene& hs, const Bvh2Buil
     else build_bvh2(prep, smin, smax, hs.bvh2);
     auto t2 = std::chrono::steady_clock::now();
     flatten_bvh4(hs.bvh2, hs.bvh4);
+    // the traversal kernels address nodes by a 32-bit byte offset (128 bytes per node)
+    if (hs.bvh4.nodes.size() >= (1u << 25)) return "too many BVH nodes (limit 2^25 - 1 four-wide nodes)";
     auto t3 = std::chrono::steady_clock::now();
     if (getenv("RTX_DEBUG_COUNTERS"))
         fprintf(stderr, "[rtx] scene preparation: triangles %.1f ms, binary BVH (%s) %.1f ms, 4-wide layout %.1f ms\n",

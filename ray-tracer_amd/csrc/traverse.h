@@ -265,7 +265,9 @@ template <bool COUNT, int BLOCK, int LDS_N>
 __device__ __forceinline__ uint32_t step_inner(const DeviceScene& sc, LaneStack<BLOCK, LDS_N>& stk, uint32_t cur,
                                                float ox, float oy, float oz, float ix, float iy, float iz, float bound, TravCount* cnt)
 {
-    const float4* np = sc.nodes4 + (size_t)cur * 8;
+    // 32-bit byte offset from the (wave-uniform) array base: the load then takes a scalar base and one
+    // vector offset register instead of a 64-bit address computed per lane (node indices stay below 2^25)
+    const float4* np = (const float4*)((const char*)sc.nodes4 + (uint32_t)(cur << 7));
     const float4 lox = np[0], loy = np[1], loz = np[2], hix = np[3], hiy = np[4], hiz = np[5];
     const float4 cf = np[6];
     if (COUNT) cnt->nodes++;
