@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Headline benchmark: closest-hit Mrays/s on the 1 M-triangle soup at 1920x1080
-(BASELINE.json configs[1]), plus the 1080p path-trace spp/s of the mixed-material scene as
+(benchmark configuration 1), plus the 1080p path-trace spp/s of the mixed-material scene as
 extra keys on the same JSON line.
 
     python bench.py --gpus N --steps K --warmup W
@@ -248,7 +248,7 @@ def cpu_baseline(pkg, scene, cam, args):
 
 def pathtrace_side(pkg, scenes, lib, core, torch, dist, world, rank, dev, args, all_reduce):
     """1080p path tracing of the mixed-material scene under the environment map
-    (BASELINE.json configs[2]); samples are split over the ranks (shard_mode 2) and the films
+    (benchmark configuration 2); samples are split over the ranks (shard_mode 2) and the films
     summed with one RCCL all-reduce at the end."""
     try:
         scene = scenes.mixed_scene(128)
