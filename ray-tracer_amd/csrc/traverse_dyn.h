@@ -29,14 +29,14 @@ constexpr int kWorkSegments = 64;
 constexpr int kWorkStride = 32;
 constexpr int kWorkSlotWords = kWorkSegments * kWorkStride;
 
-// The chunk that counter `seg` hands out as its j-th. Four consecutive chunks (four
-// neighbouring 8x8 pixel tiles of a primary-ray queue) come from the same counter, whose
-// users are the waves of a few workgroups, and eight consecutive groups of four from the
-// eight counters of one XCD (workgroup b runs on XCD b % 8 and draws from counter b % 64),
-// so that neighbouring rays meet in the same L1 / L2.
+// The chunk that counter `seg` hands out as its j-th: chunk j * kWorkSegments + c, where the eight
+// counters of one XCD (workgroup b runs on XCD b % 8 and draws from counter b % 64) own eight
+// neighbouring chunks c, so that neighbouring rays meet in the same L2. Successive chunks of one
+// counter lie kWorkSegments chunks apart: the rays a wave has in flight then come from distant
+// places of the queue, which evens out their cost (neighbouring rays cost alike).
 __device__ __forceinline__ uint32_t work_chunk(uint32_t j, uint32_t seg)
 {
-    return (((j >> 2) * (uint32_t)kWorkSegments + (seg & 7u) * 8u + (seg >> 3)) << 2) + (j & 3u);
+    return j * (uint32_t)kWorkSegments + (seg & 7u) * 8u + (seg >> 3);
 }
 
 // Tail sharing. When the work counters have run dry, the launch lasts as long as the longest
