@@ -44,7 +44,8 @@ def main():
     ap.add_argument("--ab-scene", default="soup", choices=["soup", "mixed"])
     ap.add_argument("--ab-repeat", type=int, default=1, help="A/B: trace the ray set this many times in one launch (tail measurement)")
     ap.add_argument("--ab-count", type=int, default=0, help="A/B: keep only this many rays (random subset)")
-    ap.add_argument("--ab-rays", default="primary", choices=["primary", "bounce"], help="bounce: random directions from the primary hit points")
+    ap.add_argument("--ab-rays", default="primary", choices=["primary", "bounce", "shadow"],
+                    help="bounce: random directions from the primary hit points; shadow: visibility segments from the primary hit points, half to far points in random directions (environment light), half to random points of the scene")
     args = ap.parse_args()
 
     import torch
@@ -110,6 +111,22 @@ def main():
         n = int(hit.sum().item())
         hits = torch.empty(n * HIT_BYTES, dtype=torch.uint8, device=dev)
         print(json.dumps({"bounce_rays": n}))
+    if args.variants and args.ab_rays == "shadow":
+        core.trace_closest_device(rays.data_ptr(), n, hits.data_ptr())
+        torch.cuda.synchronize()
+        r = rays.view(torch.float32).view(n, 6)
+        t = hits.view(torch.float32).view(n, 5)[:, 1]
+        hit = hits.view(torch.int32).view(n, 5)[:, 0] != -1
+        g = torch.Generator(device=dev).manual_seed(9)
+        d = torch.randn(n, 3, generator=g, device=dev)
+        d = d / d.norm(dim=1, keepdim=True)
+        p1 = r[:, :3] + r[:, 3:] * t[:, None] + 1e-3 * d
+        far = p1 + 1000.0 * d
+        near = (torch.rand(n, 3, generator=g, device=dev) * 2 - 1) * 1.2
+        pick = (torch.rand(n, 1, generator=g, device=dev) < 0.5)
+        seg = torch.cat([p1, torch.where(pick, far, near)], 1)[hit].contiguous()
+        ab_visible(pkg, lib, scene, cam, args, seg, torch, local_rank)
+        return
     if args.variants and args.ab_count and args.ab_count < n:
         g = torch.Generator(device=dev).manual_seed(11)
         keep = torch.randperm(n, generator=g, device=dev)[:args.ab_count].sort().values
@@ -211,6 +228,38 @@ def ab_variants(pkg, lib, scene, cam, args, rays, hits, n, torch, local_rank):
         t = sorted(t)
         print(json.dumps({"variant": v, "median_ms": round(t[len(t) // 2], 4), "min_ms": round(t[0], 4),
                           "mrays_per_s_median": round(n / t[len(t) // 2] / 1e3, 1)}))
+
+
+def ab_visible(pkg, lib, scene, cam, args, seg, torch, local_rank):
+    """The same interleaved comparison for the visibility kernel; the visibility bytes must agree."""
+    n = seg.shape[0]
+    vis = torch.empty(n, dtype=torch.uint8, device=seg.device)
+    print(json.dumps({"shadow_segments": n}))
+    cores = {}
+    for v in [int(x) for x in args.variants.split(",")]:
+        os.environ["RTX_VARIANT"] = str(v)
+        c = pkg.Core(local_rank, lib)
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        c.upload_scene(scene); c.set_camera(cam)
+        cores[v] = c
+    ref = None
+    times = {v: [] for v in cores}
+    for rnd in range(7):
+        for v, c in cores.items():
+            c.trace_visible_device(seg.data_ptr(), n, vis.data_ptr())
+            torch.cuda.synchronize()
+            c.timer_begin()
+            for _ in range(args.steps):
+                c.trace_visible_device(seg.data_ptr(), n, vis.data_ptr())
+            times[v].append(c.timer_end() / args.steps)
+            h = vis.clone()
+            if ref is None:
+                ref = h
+            assert torch.equal(h, ref), f"variant {v} changes the visibility"
+    for v, t in times.items():
+        t = sorted(t)
+        print(json.dumps({"variant": v, "median_ms": round(t[len(t) // 2], 4), "min_ms": round(t[0], 4),
+                          "msegments_per_s_median": round(n / t[len(t) // 2] / 1e3, 1), "visible_share": round(float(ref.float().mean()), 3)}))
 
 
 def cpu_baseline(pkg, scene, cam, args):

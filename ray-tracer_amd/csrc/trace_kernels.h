@@ -117,6 +117,18 @@ __global__ __launch_bounds__(kBlock) void k_visible(DeviceScene sc, const float*
     traverse_dyn<VisiblePolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, n, work_counter, pol, nullptr, &ts);
 }
 
+// Schedules under test (A/B harness only)
+template <int REFILL, int UNROLL, int SCHED, int SHARE>
+__global__ __launch_bounds__(kBlock) void k_visible_ab(DeviceScene sc, const float* __restrict__ p1p2, uint32_t n, uint8_t* __restrict__ visible,
+                                                       uint2* spill, uint32_t spill_stride, uint32_t* work_counter)
+{
+    __shared__ unsigned long long lds[kBlock * kLdsStack];
+    LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
+    VisiblePolicy pol{p1p2, visible};
+    __shared__ TailShare<kBlock> ts;
+    traverse_dyn<VisiblePolicy, true, false, REFILL, kBlock, kLdsStack, UNROLL, SCHED, SHARE>(sc, stk, n, work_counter, pol, nullptr, &ts);
+}
+
 // One segment, inside a kernel that loops over segments per lane (the VPL gather)
 template <int BLOCK, int LDS_N>
 __device__ __forceinline__ bool segment_visible(const DeviceScene& sc, LaneStack<BLOCK, LDS_N>& stk,
