@@ -438,7 +438,7 @@ int rtx_trace_visible_device(rtx_ctx* c, const float* p1p2, size_t n, uint8_t* v
     if (c->variant >= 2) {
 #define RTX_ABV(V, R, U, S, SH) if (c->variant == V) hipLaunchKernelGGL((k_visible_ab<R, U, S, SH>), dim3(dyn_grid_for(c, n)), dim3(kBlock), 0, c->stream, c->dscene, p1p2, \
                            (uint32_t)n, vis, c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), wc);
-        RTX_ABV(2, 20, 4, 28, 0) RTX_ABV(3, 16, 4, 24, 1) RTX_ABV(4, 24, 4, 32, 1) RTX_ABV(5, 20, 4, 20, 1) RTX_ABV(6, 20, 4, 36, 1) RTX_ABV(7, 20, 2, 28, 1)   // schedules under test
+        RTX_ABV(2, 20, 4, 28, 0) RTX_ABV(3, 16, 4, 24, 1) RTX_ABV(4, 24, 4, 32, 1)   // no tail sharing; neighbours of the default thresholds
 #undef RTX_ABV
     } else
     hipLaunchKernelGGL(k_visible, dim3(dyn_grid_for(c, n)), dim3(kBlock), 0, c->stream, c->dscene, p1p2, (uint32_t)n, vis,

@@ -261,7 +261,7 @@ __device__ __forceinline__ uint32_t pop_next(LaneStack<BLOCK, LDS_N>& stk, float
 
 // One inner node: slab-test its four slots, push the far hits, return the nearest (or the
 // next pending subtree when nothing is hit).
-template <bool COUNT, int BLOCK, int LDS_N>
+template <bool COUNT, int BLOCK, int LDS_N, int PARTIAL = 0>
 __device__ __forceinline__ uint32_t step_inner(const DeviceScene& sc, LaneStack<BLOCK, LDS_N>& stk, uint32_t cur,
                                                float ox, float oy, float oz, float ix, float iy, float iz, float bound, TravCount* cnt)
 {
@@ -298,7 +298,10 @@ __device__ __forceinline__ uint32_t step_inner(const DeviceScene& sc, LaneStack<
     }
 #define RTX_CSWAP(a, b) { bool s = key[b] < key[a]; float tk = s ? key[b] : key[a]; float uk = s ? key[a] : key[b]; \
                           uint32_t tr = s ? kref[b] : kref[a]; uint32_t ur = s ? kref[a] : kref[b]; key[a] = tk; key[b] = uk; kref[a] = tr; kref[b] = ur; }
-    RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
+    // closest hit: all four by entry distance (the order of the pending entries decides how much the best hit
+    // prunes later). PARTIAL (visibility, whose answer does not depend on the order): the nearest only.
+    RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2)
+    if (PARTIAL == 0) { RTX_CSWAP(1, 3) RTX_CSWAP(1, 2) }
 #undef RTX_CSWAP
     if (kref[3] != kEmptySlot) stk.push(kref[3], key[3]);
     if (kref[2] != kEmptySlot) stk.push(kref[2], key[2]);

@@ -216,15 +216,15 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
         if (COUNT) wave_iters[2]++;
         // every lane descends until it holds a leaf
         if (SCHED == 0) {
-            while (!(cur & kLeafBit) && cur != kDone) { if (COUNT) wave_iters[0]++; cur = step_inner<COUNT>(sc, stk, cur, ox, oy, oz, ix, iy, iz, bound, &cnt); }
+            while (!(cur & kLeafBit) && cur != kDone) { if (COUNT) wave_iters[0]++; cur = step_inner<COUNT, BLOCK, LDS_N, ANY ? 1 : 0>(sc, stk, cur, ox, oy, oz, ix, iy, iz, bound, &cnt); }
         } else if (SCHED == 1) {
-            if (!(cur & kLeafBit) && cur != kDone) { if (COUNT) wave_iters[0]++; cur = step_inner<COUNT>(sc, stk, cur, ox, oy, oz, ix, iy, iz, bound, &cnt); }
+            if (!(cur & kLeafBit) && cur != kDone) { if (COUNT) wave_iters[0]++; cur = step_inner<COUNT, BLOCK, LDS_N, ANY ? 1 : 0>(sc, stk, cur, ox, oy, oz, ix, iy, iz, bound, &cnt); }
         } else {
             // descend until SCHED lanes hold a leaf (or nobody has an inner node left)
             for (;;) {
                 const bool inner = !(cur & kLeafBit) && cur != kDone;
                 if (!__any(inner)) break;
-                if (inner) { if (COUNT) wave_iters[0]++; cur = step_inner<COUNT>(sc, stk, cur, ox, oy, oz, ix, iy, iz, bound, &cnt); }
+                if (inner) { if (COUNT) wave_iters[0]++; cur = step_inner<COUNT, BLOCK, LDS_N, ANY ? 1 : 0>(sc, stk, cur, ox, oy, oz, ix, iy, iz, bound, &cnt); }
                 if (__popcll(__ballot((cur & kLeafBit) != 0)) >= SCHED) break;
             }
         }
