@@ -338,6 +338,36 @@ __global__ __launch_bounds__(kBlock) void k_film_accumulate(WfPtrs w, int filter
     film_splat(w.film, (int)w.W, (int)w.H, filter, w.xy[2 * slot], w.xy[2 * slot + 1], ldc(w.L + 3 * slot));
 }
 
+// Box filter (Film::splat with size 0: one pixel, weight 1, RTBase/Imaging.h:318-340): the sample of slot s lands in
+// the pixel it was generated for, unless x + r rounded up to the next integer. Phase 0 adds the samples that stay in
+// their own pixel with plain loads and stores (one sample per pixel per pass, nobody else writes it in this
+// launch); phase 1, a second launch, adds the few strays with float atomics.
+__global__ __launch_bounds__(kBlock) void k_film_accumulate_box(WfPtrs w, int phase)
+{
+    const uint32_t slot = global_thread();
+    if (slot >= w.P || !(w.flags[slot] & kFlagStarted)) return;
+    uint32_t tile, x, y;
+    slot_pixel(slot, w.tiles_x, tile, x, y);
+    const float fx = w.xy[2 * slot], fy = w.xy[2 * slot + 1];
+    const int px = (int)fx, py = (int)fy;
+    const bool own = px == (int)x && py == (int)y;
+    if (own != (phase == 0)) return;
+    if (px < 0 || px >= (int)w.W || py < 0 || py >= (int)w.H) return;
+    // total weight 1, so v = L * 1 / 1 as film_splat computes it
+    const C3 v = ldc(w.L + 3 * slot) * 1.0f / 1.0f;
+    float* f = w.film + 3 * ((size_t)py * w.W + px);
+    if (phase == 0) { f[0] += v.r; f[1] += v.g; f[2] += v.b; }
+    else { atomicAdd(f, v.r); atomicAdd(f + 1, v.g); atomicAdd(f + 2, v.b); }
+}
+
+inline void launch_film_accumulate(const WfPtrs& w, int filter, dim3 grid, dim3 blk, hipStream_t s)
+{
+    if (filter == (int)RTX_FT_BOX) {
+        hipLaunchKernelGGL(k_film_accumulate_box, grid, blk, 0, s, w, 0);
+        hipLaunchKernelGGL(k_film_accumulate_box, grid, blk, 0, s, w, 1);
+    } else hipLaunchKernelGGL(k_film_accumulate, grid, blk, 0, s, w, filter);
+}
+
 // ---- draw modes: RayTracer::direct / albedo / viewNormals, RTBase/Renderer.h:536-575 -------
 __global__ __launch_bounds__(kBlock) void k_dm_shade(WfPtrs w, DeviceScene sc, PassParams pp)
 {
@@ -728,7 +758,7 @@ inline int wavefront_aov(rtx_ctx* c, float* color, float* albedo, float* normal)
         hipLaunchKernelGGL(k_closest<false>, gridT, blk, 0, s, c->dscene, (const rtx_ray*)w.ray, (const uint32_t*)w.qa, 0u, (const uint32_t*)w.cnt, w.hit,
                            c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), w.cnt + kClosestWorkBase, (unsigned long long*)nullptr);
         hipLaunchKernelGGL(k_dm_shade, gridQ, blk, 0, s, w, c->dscene, pp);
-        hipLaunchKernelGGL(k_film_accumulate, gridP, blk, 0, s, w, (int)RTX_FT_BOX);
+        launch_film_accumulate(w, (int)RTX_FT_BOX, gridP, blk, s);
     }
     return hipGetLastError() == hipSuccess ? RTX_OK : RTX_ERR_HIP;
 }
@@ -765,7 +795,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         hipLaunchKernelGGL(k_dm_shade, gridQ, blk, 0, s, w, c->dscene, pp);
         hipLaunchKernelGGL(k_shadow_accumulate, gridT, blk, 0, s, w, c->dscene, (uint32_t)kShadowCounterBase, (uint32_t)kShadowWorkBase, spill, sstride);
         if (film_wait && hipStreamWaitEvent(s, film_wait, 0) != hipSuccess) return RTX_ERR_HIP;
-        hipLaunchKernelGGL(k_film_accumulate, gridP, blk, 0, s, w, (int)st.filter);
+        launch_film_accumulate(w, (int)st.filter, gridP, blk, s);
         c->stats.samples += (uint64_t)w.W * w.H;
     } else if (st.algorithm == RTX_AL_PATH_TRACE) {
         hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, w, pp);
@@ -789,7 +819,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         }
         if (overlap && hipStreamWaitEvent(s, c->ev_shadow[lane], 0) != hipSuccess) return RTX_ERR_HIP;
         if (film_wait && hipStreamWaitEvent(s, film_wait, 0) != hipSuccess) return RTX_ERR_HIP;
-        hipLaunchKernelGGL(k_film_accumulate, gridP, blk, 0, s, w, (int)st.filter);
+        launch_film_accumulate(w, (int)st.filter, gridP, blk, s);
         c->stats.samples += (uint64_t)w.W * w.H;
     } else if (st.algorithm == RTX_AL_LIGHT_TRACE) {
         hipLaunchKernelGGL(k_lt_emit, gridP, blk, 0, s, w, c->dscene, c->dcam, pp);
@@ -830,7 +860,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         closest(w.qa, 0);
         hipLaunchKernelGGL(k_ir_gather, gridQ, blk, 0, s, w, c->dscene, pp, spill, sstride);
         if (film_wait && hipStreamWaitEvent(s, film_wait, 0) != hipSuccess) return RTX_ERR_HIP;
-        hipLaunchKernelGGL(k_film_accumulate, gridP, blk, 0, s, w, (int)st.filter);
+        launch_film_accumulate(w, (int)st.filter, gridP, blk, s);
         c->stats.samples += (uint64_t)w.W * w.H;
     }
     if (hipGetLastError() != hipSuccess) return RTX_ERR_HIP;
