@@ -194,3 +194,23 @@ def test_ragged_batch_sizes_of_the_dynamic_fetch(pkg, lib, core, orc, scenes):
     for n in (1, 63, 65, 257, 300_007):
         assert np.array_equal(core.trace_visible(seg[:n]), vis[:n])
     osc.close()
+
+
+@pytest.mark.parametrize("seed,n_tris,size", [(101, 30_000, 0.02), (102, 8_000, 0.3), (103, 60_000, 0.05), (104, 500, 1.0)])
+def test_randomised_soups_closest_and_visible(pkg, lib, core, orc, scenes, seed, n_tris, size):
+    """Different triangle sizes change how heavy-tailed the per-ray cost is (large triangles: deep
+    overlapping boxes, long rays beside short ones in one wave), which is what the work sharing at
+    the end of a launch reacts to; hits and visibility must not depend on it."""
+    sc = scenes.soup(n_tris, seed=seed, size=size)
+    core.upload_scene(sc)
+    osc = orc.scene(sc)
+    rays = np.concatenate([_rand_rays(pkg, 50_000, seed), _axis_rays(pkg, 6_000, seed + 1)])
+    want = osc.trace_closest(rays, threads=8)
+    _assert_hits_equal(core.trace_closest(rays), want)
+    for n in (17, 1000, 20_001):       # launches that are all tail
+        _assert_hits_equal(core.trace_closest(rays[:n]), want[:n])
+    seg = np.random.RandomState(seed).uniform(-1.3, 1.3, (40_000, 6)).astype(np.float32)
+    vis = osc.trace_visible(seg, threads=8)
+    assert np.array_equal(core.trace_visible(seg), vis)
+    assert np.array_equal(core.trace_visible(seg[:333]), vis[:333])
+    osc.close()
