@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pathtrace", action="store_true")
-    ap.add_argument("--pt-spp", type=int, default=16, help="passes of the path-trace side measurement")
+    ap.add_argument("--pt-spp", type=int, default=64, help="passes of the path-trace side measurement")
     ap.add_argument("--variants", default="", help="A/B: comma list of RTX_VARIANT values, interleaved rounds in one process")
     ap.add_argument("--ab-scene", default="soup", choices=["soup", "mixed"])
     ap.add_argument("--ab-repeat", type=int, default=1, help="A/B: trace the ray set this many times in one launch (tail measurement)")
