@@ -81,6 +81,8 @@ struct DeviceScene {
     const float* env_texels;     // RGB triples
     const float* env_cdf_rows;   // [h]   TabulatedDistribution::cdfRows
     const float* env_cdf_cols;   // [h*w] TabulatedDistribution::cdfCols
+    const uint32_t* env_guide_rows;   // [h + 1]       first row whose CDF value is >= b / h (0xFFFFFFFF: no guide)
+    const uint32_t* env_guide_cols;   // [h * (w + 1)] the same per row of cdfCols
     float env_inv_w, env_inv_h;
     float scene_centre[3], scene_radius;   // SceneBounds, SceneLoader.h:387-388
 };

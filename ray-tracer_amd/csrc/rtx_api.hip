@@ -164,6 +164,8 @@ int rtx_upload_scene(rtx_ctx* c, const rtx_scene_desc* d)
     if ((rc = upload(c->b_env_texels, h.env_texels, s))) return rc;
     if ((rc = upload(c->b_env_rows, h.env_cdf_rows, s))) return rc;
     if ((rc = upload(c->b_env_cols, h.env_cdf_cols, s))) return rc;
+    if ((rc = upload(c->b_env_guide_rows, h.env_guide_rows, s))) return rc;
+    if ((rc = upload(c->b_env_guide_cols, h.env_guide_cols, s))) return rc;
     HIP_TRY(hipStreamSynchronize(s));
 
     DeviceScene& ds = c->dscene;
@@ -173,6 +175,7 @@ int rtx_upload_scene(rtx_ctx* c, const rtx_scene_desc* d)
     for (int a = 0; a < 3; a++) { ds.root_min[a] = h.bvh4.root_min[a]; ds.root_max[a] = h.bvh4.root_max[a]; ds.bg_emission[a] = h.bg_emission[a]; ds.scene_centre[a] = h.scene_centre[a]; }
     ds.bg_kind = h.bg_kind; ds.env_w = h.env_w; ds.env_h = h.env_h;
     ds.env_texels = c->b_env_texels.as<float>(); ds.env_cdf_rows = c->b_env_rows.as<float>(); ds.env_cdf_cols = c->b_env_cols.as<float>();
+    ds.env_guide_rows = c->b_env_guide_rows.as<uint32_t>(); ds.env_guide_cols = c->b_env_guide_cols.as<uint32_t>();
     ds.env_inv_w = h.env_w ? 1.0f / (float)h.env_w : 0.f; ds.env_inv_h = h.env_h ? 1.0f / (float)h.env_h : 0.f;
     ds.scene_radius = h.scene_radius;
 

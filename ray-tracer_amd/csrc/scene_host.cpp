@@ -111,6 +111,24 @@ void camera_look_at(rtx_camera& c, const float from_[3], const float to_[3], con
     c.view_dir[0] = vd.x; c.view_dir[1] = vd.y; c.view_dir[2] = vd.z;
 }
 
+// Guide table of a CDF with n entries: guide[b] = first index whose value is >= b / n (clamped to n - 1), for
+// b = 0..n. TabulatedDistribution::binarySearch (Lights.h:210-230) returns the first index whose value is >= the
+// argument, which does not depend on the probing order when the table is non-decreasing; the device then only has
+// to search between two guide entries. A table that is not non-decreasing and finite (an all-black row divides by
+// zero) gets guide[0] = 0xFFFFFFFF and is searched the reference's way.
+static void cdf_guide(const float* cdf, uint32_t n, uint32_t* guide)
+{
+    bool ok = n > 0 && std::isfinite(cdf[0]);
+    for (uint32_t i = 1; ok && i < n; i++) ok = std::isfinite(cdf[i]) && cdf[i] >= cdf[i - 1];
+    if (!ok) { for (uint32_t b = 0; b <= n; b++) guide[b] = 0xFFFFFFFFu; return; }
+    uint32_t i = 0;
+    for (uint32_t b = 0; b <= n; b++) {
+        const float v = (float)b / (float)n;
+        while (i < n - 1 && cdf[i] < v) i++;
+        guide[b] = i;
+    }
+}
+
 std::string prepare_scene(const rtx_scene_desc& d, HostScene& hs, const Bvh2BuildFn& build)
 {
     if (d.n_triangles >= kMaxTriangles) return "too many triangles (limit 2^27 - 1)";
@@ -240,6 +258,12 @@ std::string prepare_scene(const rtx_scene_desc& d, HostScene& hs, const Bvh2Buil
             hs.env_cdf_rows[y] = accumRow;
         }
         bgPower = (float)(hs.env_avg_lum * 4.0f * kPi);                                            // Lights.h:378-380
+        // guide tables for the device's CDF look-ups (same result as the full binary search, fewer dependent loads)
+        hs.env_guide_rows.assign((size_t)H + 1, 0u); hs.env_guide_cols.assign((size_t)H * (W + 1), 0u);
+        cdf_guide(hs.env_cdf_rows.data(), H, hs.env_guide_rows.data());
+        parallel_ranges(H, [&](size_t y0, size_t y1) {
+            for (size_t y = y0; y < y1; y++) cdf_guide(&hs.env_cdf_cols[y * W], W, &hs.env_guide_cols[y * (W + 1)]);
+        });
     } else {
         hs.bg_kind = 1; hs.env_w = hs.env_h = 0;
         for (int k = 0; k < 3; k++) hs.bg_emission[k] = d.background[k];

@@ -23,6 +23,7 @@ struct HostScene {
     float bg_emission[3] = {0, 0, 0};
     int env_w = 0, env_h = 0;
     std::vector<float> env_texels, env_cdf_rows, env_cdf_cols;
+    std::vector<uint32_t> env_guide_rows, env_guide_cols;   // [h + 1], [h * (w + 1)]: see cdf_guide() in scene_host.cpp
     float env_avg_lum = 0;
     float scene_centre[3] = {0, 0, 0}, scene_radius = 0;
     float build_ms = 0;

@@ -382,10 +382,24 @@ RTX_DI int cdf_search(const float* cdf, int n, float value)                     
     while (left < right) { int mid = left + (right - left) / 2; if (cdf[mid] < value) left = mid + 1; else right = mid; }
     return left;
 }
+// The same index through a guide table (guide[b] = first index whose value is >= b / n): the answer for `value`
+// lies between the guide entries two buckets below and three above the bucket value * n falls in (the slack covers
+// the rounding of that product and of b / n), so the search starts on a handful of entries instead of n.
+RTX_DI int cdf_search_guided(const float* cdf, int n, const uint32_t* guide, float value)
+{
+    if (guide[0] == 0xFFFFFFFFu) return cdf_search(cdf, n, value);
+    if (value <= cdf[0]) return 0;
+    if (value >= cdf[n - 1]) return n - 1;
+    int b = (int)(value * (float)n);
+    b = b < 0 ? 0 : (b > n - 1 ? n - 1 : b);
+    int left = (int)guide[b - 2 < 0 ? 0 : b - 2], right = (int)guide[b + 3 > n ? n : b + 3];
+    while (left < right) { int mid = left + (right - left) / 2; if (cdf[mid] < value) left = mid + 1; else right = mid; }
+    return left;
+}
 RTX_DI V3 env_sample(const DeviceScene& sc, Rng& rng, C3& emitted, float& pdf)    // Lights.h:252-277, 330-336
 {
-    unsigned row = cdf_search(sc.env_cdf_rows, sc.env_h, rng.next());
-    unsigned col = cdf_search(sc.env_cdf_cols + (size_t)row * sc.env_w, sc.env_w, rng.next());
+    unsigned row = cdf_search_guided(sc.env_cdf_rows, sc.env_h, sc.env_guide_rows, rng.next());
+    unsigned col = cdf_search_guided(sc.env_cdf_cols + (size_t)row * sc.env_w, sc.env_w, sc.env_guide_cols + (size_t)row * (sc.env_w + 1), rng.next());
     pdf = tab_pdf(sc, row, col);
     float u = (float)col * sc.env_inv_w;
     float v = (float)row * sc.env_inv_h;
