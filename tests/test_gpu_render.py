@@ -72,6 +72,26 @@ def test_path_trace_per_sample_parity_env_mis(pkg, lib, core, orc, scenes):
         assert g.mean() > 0.01
 
 
+@pytest.mark.parametrize("case", ["odd_size", "black_rows"])
+def test_env_sampling_tables_of_any_shape(pkg, lib, core, orc, scenes, case):
+    """Environment maps whose size is not a power of two, and with all-black rows and columns
+    (flat stretches in the row table, a column table that is 0/0 throughout): the device's
+    guided table look-up must pick the same texel as the reference's binary search."""
+    base = scenes.mixed_scene(16, (100, 37) if case == "odd_size" else (96, 40))
+    scene = base
+    if case == "black_rows":
+        env = base.env.copy()
+        env[28:] = 0.0
+        env[:, 10:20] = 0.0
+        scene = pkg.SceneArrays(base.positions, base.normals, base.uvs, base.material_index, base.materials, base.textures, env=env)
+    st, osc = _setup(pkg, lib, core, orc, scene, scenes.mixed_camera(), 96, 54, total_spp=2, seed=9, use_mis=1)
+    r = osc.renderer(st, threads=8, counter_rng=True)
+    core.render_passes(2); r.render_passes(2)
+    g, _, _ = core.film(); o, _, _ = r.film()
+    _assert_films_match(g, o, f"env {case}", frac=0.01)
+    assert np.nan_to_num(g).mean() > 0.01
+
+
 def test_max_bounces_zero_and_no_light_hits(pkg, lib, core, orc, scenes):
     for mb, chl in ((0, 1), (1, 0), (2, 1)):
         st, osc = _setup(pkg, lib, core, orc, scenes.cornell_box("mixed"), scenes.cornell_camera(), 64, 64,
