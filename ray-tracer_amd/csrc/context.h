@@ -26,6 +26,21 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
+// Pinned host memory for the host-pointer entry points: two slots per direction, so that the host's copy into
+// (out of) one slot runs beside the DMA of the other.
+struct PinBuf {
+    static constexpr size_t kSlot = 8u << 20;
+    char* p = nullptr; hipEvent_t ev[2] = {nullptr, nullptr};
+    ~PinBuf() { if (p) (void)hipHostFree(p); for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
+    hipError_t ensure()
+    {
+        if (p) return hipSuccess;
+        hipError_t e = hipHostMalloc((void**)&p, 2 * kSlot, hipHostMallocDefault);
+        for (int i = 0; e == hipSuccess && i < 2; i++) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+        return e;
+    }
+};
+
 struct WavefrontBuffers;   // path-tracing state (wavefront.h)
 
 } // namespace rtx
@@ -48,6 +63,7 @@ struct rtx_ctx {
     rtx::DevBuf b_spill;           // global part of the traversal stacks
     uint32_t spill_entries = 0;    // entries per lane in b_spill
     rtx::DevBuf b_io_a, b_io_b;    // staging for the host-pointer entry points
+    rtx::PinBuf pin_in, pin_out;
     rtx::DevBuf b_counters;
 
     // progressive state
