@@ -129,7 +129,7 @@ typedef struct {
     uint64_t shadow_rays;      /* rays through the visibility kernel                      */
     uint64_t samples;          /* pixel samples started                                   */
     uint32_t bvh2_nodes, bvh2_depth, bvh4_nodes, bvh4_depth, n_lights;
-    float build_ms;            /* host BVH build + flatten                                */
+    float build_ms;            /* BVH build (device, or host under RTX_BVH_BUILD=host) + flatten */
 } rtx_stats;
 
 /* ---- context ---------------------------------------------------------------------- */
@@ -140,8 +140,11 @@ int rtx_create(rtx_ctx** out, int device);
 void rtx_destroy(rtx_ctx* ctx);
 const char* rtx_last_error(void);
 
-/* Work is enqueued on `hip_stream` (a hipStream_t) instead of the context's own stream;
- * NULL restores the own stream. For callers that time or order work themselves. */
+/* Work is enqueued on `hip_stream` (a hipStream_t; NULL is HIP's null stream, as everywhere in HIP)
+ * instead of the context's own stream, which is created non-blocking and is therefore NOT ordered
+ * against the null stream; RTX_STREAM_OWN restores it. For callers that time or order work
+ * themselves. */
+#define RTX_STREAM_OWN ((void*)(intptr_t)-1)
 int rtx_set_stream(rtx_ctx* ctx, void* hip_stream);
 int rtx_synchronize(rtx_ctx* ctx);
 
@@ -204,10 +207,6 @@ int rtx_update_tile_samples(rtx_ctx* ctx);
 /* Overwrite SPP (after a cross-GPU sum of films rendered with shard_mode 2). */
 int rtx_set_spp(rtx_ctx* ctx, int spp);
 
-/* ---- ray queries ------------------------------------------------------------------ */
-
-/* Scene::traverse, RTBase/Scene.h:137-141 → BVHTree::traverse, RTBase/Geometry.h:506-566,
- * for n rays in host memory. */
 /* RayTracer::createAOV, RTBase/Renderer.h:786-820: the three input planes of the denoiser, W*H*3
  * floats each, any pointer may be NULL. color = film / spp (per-tile spp once adaptive sampling
  * has taken over, :798-802); albedo = RayTracer::albedo (:553-565) and normal =
@@ -216,6 +215,10 @@ int rtx_set_spp(rtx_ctx* ctx, int spp);
 int rtx_create_aov(rtx_ctx* ctx, float* color, float* albedo, float* normal);
 int rtx_create_aov_device(rtx_ctx* ctx, float* color, float* albedo, float* normal);
 
+/* ---- ray queries ------------------------------------------------------------------ */
+
+/* Scene::traverse, RTBase/Scene.h:137-141 → BVHTree::traverse, RTBase/Geometry.h:506-566,
+ * for n rays in host memory. */
 int rtx_trace_closest(rtx_ctx* ctx, const rtx_ray* rays, size_t n, rtx_hit* hits);
 /* Same, rays and hits already in device memory (no copies, asynchronous on the stream). */
 int rtx_trace_closest_device(rtx_ctx* ctx, const rtx_ray* rays_dev, size_t n, rtx_hit* hits_dev);
@@ -258,7 +261,7 @@ int rtx_timer_end(rtx_ctx* ctx, float* ms);
 
 /* Algorithmic traffic of the closest-hit kernel for the rays of the last
  * rtx_trace_closest* call, counted by an instrumented device pass over the same layout:
- * wide nodes visited (128 B each) and triangles tested (48 B each), summed over rays. */
+ * wide nodes visited (128 B each) and triangles tested (36 B each), summed over rays. */
 int rtx_count_closest_work(rtx_ctx* ctx, const rtx_ray* rays_dev, size_t n,
                            uint64_t* nodes_visited, uint64_t* tris_tested);
 

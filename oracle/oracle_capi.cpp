@@ -171,6 +171,8 @@ void orc_film_read(orc_renderer* r, float* rgbs, int* spp, uint32_t* tiles)
 // Film write access so calculateTileSamples can be checked on a fixed film
 void orc_film_write(orc_renderer* r, const float* rgbs, int spp) { Film& f = r->r.film; std::memcpy((void*)f.film.data(), rgbs, f.film.size() * sizeof(RGB)); f.SPP = spp; }
 void orc_calculate_tile_samples(orc_renderer* r) { r->r.calculateTileSamples(); }
+// RayTracer::tileSamples (Renderer.h:41) set from outside: targets gathered from the ranks of a sharded render
+void orc_tile_samples_write(orc_renderer* r, const uint32_t* tiles) { for (size_t i = 0; i < r->r.tileSamples.size(); i++) r->r.tileSamples[i] = tiles[i]; }
 // RayTracer::createAOV, Renderer.h:786-820
 void orc_create_aov(orc_renderer* r, float* color, float* albedo, float* normal) { r->r.createAOV(color, albedo, normal); }
 // Film::splat (Imaging.h:318-340) of n samples (x, y, r, g, b) in order

@@ -816,7 +816,7 @@ struct Renderer {
         unsigned paths = st.vpl_rays_per_tile * st.num_threads;
         vpls.clear();
         for (unsigned pidx = 0; pidx < paths; pidx++) {
-            if (counterRng) { CounterSampler cs(st.seed, RTX_STREAM_VPL, pidx, (uint32_t)film.SPP); traceVPLPath(&cs, vpls); }
+            if (counterRng) { CounterSampler cs(st.seed, RTX_STREAM_VPL, pidx, globalSample()); traceVPLPath(&cs, vpls); }
             else traceVPLPath(&mt[pidx % numThreads], vpls);
         }
     }
@@ -873,8 +873,11 @@ struct Renderer {
         RGB col = st.algorithm == RTX_AL_PATH_TRACE ? pathTrace(ray, s) : radiosityLightPass(ray);
         film.splat(px, py, col);
     }
-    bool tileSkipped(unsigned i) const                                                     // Renderer.h:682-687
-    { return film.SPP > (int)st.init_spp && film.SPP > (int)tileSamples[i] && st.algorithm != RTX_AL_LIGHT_TRACE; }
+    // shard_mode 2 (samples split over ranks): this rank's k-th pass renders global sample rank+1 + (k-1)*world
+    uint32_t globalSample() const
+    { return (st.shard_mode == 2 && st.shard_world > 1) ? (uint32_t)(film.SPP - 1) * (uint32_t)st.shard_world + (uint32_t)st.shard_rank + 1u : (uint32_t)film.SPP; }
+    bool tileSkipped(unsigned i) const                                                     // Renderer.h:682-687, on the global sample count
+    { const int cur = (int)globalSample(); return cur > (int)st.init_spp && cur > (int)tileSamples[i] && st.algorithm != RTX_AL_LIGHT_TRACE; }
     bool sharded(unsigned tile) const { return st.shard_mode == 1 && st.shard_world > 1 && (int)(tile % (unsigned)st.shard_world) != st.shard_rank; }
 
     // ---- renderMT, Renderer.h:753-782 (tile queue on an atomic counter, Renderer.h:677-751) ----
@@ -892,9 +895,7 @@ struct Renderer {
                 for (unsigned y = sy; y < ey; y++) for (unsigned x = sx; x < ex; x++) {
                     if (counterRng) {
                         uint32_t stream = st.algorithm == RTX_AL_LIGHT_TRACE && st.draw_mode == RTX_DM_ALGORITHM ? RTX_STREAM_LIGHT : RTX_STREAM_CAMERA;
-                        // shard_mode 2: this rank renders global sample indices rank+1, rank+1+world, ...
-                        uint32_t sample = (st.shard_mode == 2 && st.shard_world > 1) ? (uint32_t)(film.SPP - 1) * (uint32_t)st.shard_world + (uint32_t)st.shard_rank + 1u : (uint32_t)film.SPP;
-                        cs.reset(st.seed, stream, y * film.width + x, sample);
+                        cs.reset(st.seed, stream, y * film.width + x, globalSample());
                         pixel(x, y, &cs);
                     } else pixel(x, y, &mt[id]);
                 }

@@ -58,6 +58,7 @@ class Oracle:
         lib.orc_film_read.argtypes = [vp, vp, C.POINTER(C.c_int), vp]
         lib.orc_film_write.argtypes = [vp, vp, C.c_int]
         lib.orc_calculate_tile_samples.argtypes = [vp]
+        lib.orc_tile_samples_write.argtypes = [vp, vp]
         lib.orc_create_aov.argtypes = [vp, vp, vp, vp]
         lib.orc_film_splat.argtypes = [vp, vp, C.c_size_t]
         lib.orc_rng.argtypes = [C.c_uint32] * 5; lib.orc_rng.restype = C.c_float
@@ -205,6 +206,10 @@ class OracleRenderer:
 
     def calculate_tile_samples(self):
         self.lib.orc_calculate_tile_samples(self.h)
+
+    def tile_samples_write(self, tiles):
+        t = np.ascontiguousarray(tiles, np.uint32)
+        self.lib.orc_tile_samples_write(self.h, _p(t))
 
     def splat(self, xyrgb):
         a = np.ascontiguousarray(xyrgb, np.float32).reshape(-1, 5)

@@ -55,6 +55,8 @@ extern "C" {
 
 const char* rtx_last_error(void) { return g_err; }
 
+static int create_resources(rtx_ctx* c, int device);
+
 int rtx_create(rtx_ctx** out, int device)
 {
     if (!out) return fail(RTX_ERR_INVALID, "out is null");
@@ -64,6 +66,14 @@ int rtx_create(rtx_ctx** out, int device)
     HIP_TRY(hipSetDevice(device));
     rtx_ctx* c = new (std::nothrow) rtx_ctx;
     if (!c) return fail(RTX_ERR_NOMEM, "out of host memory");
+    const int rc = create_resources(c, device);
+    if (rc) { rtx_destroy(c); return rc; }      // streams, events and buffers made so far are released (g_err keeps the cause)
+    *out = c;
+    return RTX_OK;
+}
+
+static int create_resources(rtx_ctx* c, int device)
+{
     c->device = device;
     c->variant = 1;
     if (const char* v = getenv("RTX_VARIANT")) c->variant = atoi(v);
@@ -99,7 +109,6 @@ int rtx_create(rtx_ctx** out, int device)
     s.use_mis = 0; s.can_hit_light = 0; s.adaptive_sampling = 0;
     s.max_bounces = 5; s.init_spp = 10; s.total_spp = 8192; s.vpl_rays_per_tile = 1; s.num_threads = 3;
     s.seed = 1; s.shard_mode = 0; s.shard_rank = 0; s.shard_world = 1;
-    *out = c;
     return RTX_OK;
 }
 
@@ -107,7 +116,7 @@ void rtx_destroy(rtx_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     wavefront_release(c);
     for (int i = 0; i < kPipeline; i++) {
         if (c->pipe_stream[i]) (void)hipStreamDestroy(c->pipe_stream[i]);
@@ -129,7 +138,7 @@ int rtx_set_stream(rtx_ctx* c, void* s)
 {
     CTX_TRY(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = s == RTX_STREAM_OWN ? c->own_stream : (hipStream_t)s;      // NULL is HIP's null stream, as for any hipStream_t
     return RTX_OK;
 }
 
@@ -457,13 +466,16 @@ int rtx_trace_closest(rtx_ctx* c, const rtx_ray* rays, size_t n, rtx_hit* hits)
     CTX_TRY(c);
     if (n == 0) return RTX_OK;
     if (!rays || !hits) return fail(RTX_ERR_INVALID, "null buffer");
+    if (!c->have_scene) return fail(RTX_ERR_STATE, "no scene uploaded");
+    if (n > 0xF0000000ull) return fail(RTX_ERR_INVALID, "too many rays in one call");
     HIP_TRY(c->b_io_a.ensure(n * sizeof(rtx_ray)));
     HIP_TRY(c->b_io_b.ensure(n * sizeof(rtx_hit)));
     int rc = stage_in(c, rays, n * sizeof(rtx_ray), c->b_io_a.p);
-    if (rc) return rc;
-    rc = rtx_trace_closest_device(c, c->b_io_a.as<rtx_ray>(), n, c->b_io_b.as<rtx_hit>());
-    if (rc) return rc;
-    return stage_out(c, c->b_io_b.p, n * sizeof(rtx_hit), hits);
+    if (!rc) rc = rtx_trace_closest_device(c, c->b_io_a.as<rtx_ray>(), n, c->b_io_b.as<rtx_hit>());
+    if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }     // no DMA may still read the pinned slots after the call
+    rc = stage_out(c, c->b_io_b.p, n * sizeof(rtx_hit), hits);
+    if (rc) (void)hipStreamSynchronize(c->stream);
+    return rc;
 }
 
 int rtx_trace_visible_device(rtx_ctx* c, const float* p1p2, size_t n, uint8_t* vis)
@@ -493,13 +505,16 @@ int rtx_trace_visible(rtx_ctx* c, const float* p1p2, size_t n, uint8_t* vis)
     CTX_TRY(c);
     if (n == 0) return RTX_OK;
     if (!p1p2 || !vis) return fail(RTX_ERR_INVALID, "null buffer");
+    if (!c->have_scene) return fail(RTX_ERR_STATE, "no scene uploaded");
+    if (n > 0xF0000000ull) return fail(RTX_ERR_INVALID, "too many segments in one call");
     HIP_TRY(c->b_io_a.ensure(n * 6 * sizeof(float)));
     HIP_TRY(c->b_io_b.ensure(n));
     int rc = stage_in(c, p1p2, n * 6 * sizeof(float), c->b_io_a.p);
-    if (rc) return rc;
-    rc = rtx_trace_visible_device(c, c->b_io_a.as<float>(), n, c->b_io_b.as<uint8_t>());
-    if (rc) return rc;
-    return stage_out(c, c->b_io_b.p, n, vis);
+    if (!rc) rc = rtx_trace_visible_device(c, c->b_io_a.as<float>(), n, c->b_io_b.as<uint8_t>());
+    if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+    rc = stage_out(c, c->b_io_b.p, n, vis);
+    if (rc) (void)hipStreamSynchronize(c->stream);
+    return rc;
 }
 
 int rtx_generate_primary_rays_device(rtx_ctx* c, rtx_ray* rays, uint32_t* pixel, size_t cap)

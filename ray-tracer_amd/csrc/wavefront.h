@@ -555,7 +555,7 @@ __global__ __launch_bounds__(kBlock) void k_vpl_emit(WfPtrs w, DeviceScene sc, P
     const uint32_t j = global_thread();
     bool live = false;
     if (j < n_paths && sc.n_lights > 0) {
-        Rng rng; rng.key = rtx_rng_key(pp.st.seed, RTX_STREAM_VPL, j, (uint32_t)pp.spp); rng.dim = 0;
+        Rng rng; rng.key = rtx_rng_key(pp.st.seed, RTX_STREAM_VPL, j, pp.sample_index); rng.dim = 0;
         float pmf; const LightDev& light = sample_light(sc, rng, pmf);
         float pdfPos, pdfDir;
         V3 p = light_sample_position(sc, light, rng, pdfPos);
