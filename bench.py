@@ -48,6 +48,10 @@ def main():
                     help="bounce: random directions from the primary hit points; shadow: visibility segments from the primary hit points, half to far points in random directions (environment light), half to random points of the scene")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks here, before this process touches a GPU
+        sys.exit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
 
@@ -79,8 +83,9 @@ def main():
     scenes = importlib.import_module("ray-tracer_amd.scenes")
     lib = pkg.load_library()
     core = pkg.Core(local_rank, lib)
-    # enqueue on torch's current stream so torch events / synchronize see the kernels
-    core.set_stream(torch.cuda.current_stream().cuda_stream)
+    # the core keeps its own (non-blocking) stream: kernels are timed with HIP events on that stream
+    # (rtx_timer_*), and every hand-over between torch's work and the core's is a device-wide
+    # torch.cuda.synchronize()
 
     if args.variants and args.ab_scene == "mixed":
         scene = scenes.mixed_scene(128)
@@ -200,6 +205,26 @@ def main():
         dist.destroy_process_group()
 
 
+def spawn_ranks(n: int) -> int:
+    """One child process per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, the same command
+    line otherwise (what torch.distributed.run would start); rank 0 prints the JSON line. The parent
+    never initialises a GPU. Returns the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def ab_variants(pkg, lib, scene, cam, args, rays, hits, n, torch, local_rank):
     """Interleaved rounds of the closest-hit kernel under different RTX_VARIANT schedules
     (one context each, same rays), median and min kernel ms per variant."""
@@ -207,7 +232,6 @@ def ab_variants(pkg, lib, scene, cam, args, rays, hits, n, torch, local_rank):
     for v in [int(x) for x in args.variants.split(",")]:
         os.environ["RTX_VARIANT"] = str(v)
         c = pkg.Core(local_rank, lib)
-        c.set_stream(torch.cuda.current_stream().cuda_stream)
         c.upload_scene(scene); c.set_camera(cam)
         cores[v] = c
     ref = None
@@ -239,7 +263,6 @@ def ab_visible(pkg, lib, scene, cam, args, seg, torch, local_rank):
     for v in [int(x) for x in args.variants.split(",")]:
         os.environ["RTX_VARIANT"] = str(v)
         c = pkg.Core(local_rank, lib)
-        c.set_stream(torch.cuda.current_stream().cuda_stream)
         c.upload_scene(scene); c.set_camera(cam)
         cores[v] = c
     ref = None

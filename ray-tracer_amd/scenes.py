@@ -65,7 +65,7 @@ def _box(lo, hi):
     return t
 
 
-def cornell_box(materials="diffuse"):
+def cornell_box(materials="diffuse", background=(0.0, 0.0, 0.0), emissive=True):
     """Cornell-box stand-in for scene 0 (scenes/cornell-box, RTBase/Main.cpp:39): five walls,
     two boxes, one emissive quad Le = (17, 12, 4), black background.
 
@@ -73,6 +73,11 @@ def cornell_box(materials="diffuse"):
     Conductor so that every BSDF of RTBase/Materials.h is exercised in a tiny scene;
     materials="next" uses the remaining classes instead: Oren-Nayar walls, a Dielectric tall
     box, a Layered(Glass) short box and a Layered(Plastic) small box.
+
+    background: the constant background colour (BackgroundColour, RTBase/Lights.h:86-135); a non-black
+    one joins the light list (RTBase/Scene.h:165-168) and shines in through the open front.
+    emissive=False turns the ceiling quad into a plain diffuse one, so that the background is the
+    only light.
     """
     tris, mat = [], []
 
@@ -98,7 +103,7 @@ def cornell_box(materials="diffuse"):
     tex = [WHITE * 0.73, np.array([[[0.63, 0.065, 0.05]]], np.float32), np.array([[[0.14, 0.45, 0.091]]], np.float32),
            WHITE.copy()]
     mats = [material(_pkg.BSDF_DIFFUSE, 0), material(_pkg.BSDF_DIFFUSE, 1), material(_pkg.BSDF_DIFFUSE, 2),
-            material(_pkg.BSDF_DIFFUSE, 0, emission=(17, 12, 4)),
+            material(_pkg.BSDF_DIFFUSE, 0, emission=(17, 12, 4) if emissive else (0, 0, 0)),
             material(_pkg.BSDF_MIRROR, 3),
             material(_pkg.BSDF_PLASTIC, 1, roughness=0.1, int_ior=1.5, ext_ior=1.0),
             material(_pkg.BSDF_GLASS, 3, int_ior=1.5, ext_ior=1.0),
@@ -107,12 +112,12 @@ def cornell_box(materials="diffuse"):
         L = _pkg.BSDF_LAYERED
         mats = [material(_pkg.BSDF_ORENNAYAR, 0, roughness=0.6), material(_pkg.BSDF_ORENNAYAR, 1, roughness=0.3),
                 material(_pkg.BSDF_ORENNAYAR, 2, roughness=1.0),
-                material(_pkg.BSDF_DIFFUSE, 0, emission=(17, 12, 4)),
+                material(_pkg.BSDF_DIFFUSE, 0, emission=(17, 12, 4) if emissive else (0, 0, 0)),
                 material(_pkg.BSDF_DIELECTRIC, 3, roughness=0.2, int_ior=1.5, ext_ior=1.0),
                 material(_pkg.BSDF_ORENNAYAR | L, 1, roughness=0.45),
                 material(_pkg.BSDF_GLASS | L, 3, int_ior=1.5, ext_ior=1.0),
                 material(_pkg.BSDF_PLASTIC | L, 2, roughness=0.1, int_ior=1.5, ext_ior=1.0)]
-    return SceneArrays(pos, nrm, uv, np.array(mat, np.uint32), mats, tex)
+    return SceneArrays(pos, nrm, uv, np.array(mat, np.uint32), mats, tex, background=background)
 
 
 def cornell_camera():
@@ -233,3 +238,35 @@ def terrain(grid=2236, seed=7):
 
 def terrain_camera():
     return dict(frm=(0.0, 5.0, 14.0), to=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=45.0)
+
+
+def deep_chains(k=55, ratio=2.0, arms=3):
+    """Small triangles at geometrically growing distances along the three axes. Every SAH split peels
+    a few of the farthest off one arm, so the reference's tree is a caterpillar about 40 levels deep
+    (k=55, ratio 2: binary depth 40, 4-wide depth 14) from only 165 triangles: the scene that
+    exercises the deepest traversal stacks."""
+    g = float(ratio) ** np.arange(1, k + 1)
+    one = np.ones(k)
+    c = np.concatenate([np.stack([g, one, one], 1), np.stack([one, g, one], 1), np.stack([one, one, g], 1)][:arms])
+    pos = np.repeat(c[:, None, :], 3, 1).astype(np.float32)
+    pos[:, 1, 0] += 0.25; pos[:, 2, 1] += 0.25; pos[:, 2, 2] += 0.25
+    uv = np.zeros((len(pos), 3, 2), np.float32)
+    nrm = np.repeat(_face_normals(pos)[:, None, :], 3, axis=1)
+    return SceneArrays(pos, nrm, uv, np.zeros(len(pos), np.uint32), [material(_pkg.BSDF_DIFFUSE, 0)], [WHITE * 0.8])
+
+
+def transformed(scene, scale=1.0, offset=(0.0, 0.0, 0.0)):
+    """The same scene with every vertex at p * scale + offset (fp32, so large offsets quantise the
+    geometry; degenerate results are dropped like the loader does)."""
+    pos = (scene.positions * np.float32(scale) + np.asarray(offset, np.float32)).astype(np.float32)
+    pos, nrm, uv, mi = _drop_degenerate(pos, scene.normals, scene.uvs, scene.material_index)
+    bg = tuple(scene.desc.background)
+    return SceneArrays(pos, nrm, uv, mi, scene.materials, scene.textures, env=scene.env, background=bg)
+
+
+def transformed_camera(cam_kw, scale=1.0, offset=(0.0, 0.0, 0.0)):
+    o = np.asarray(offset, np.float64)
+    out = dict(cam_kw)
+    out["frm"] = tuple(float(v) for v in np.asarray(cam_kw["frm"], np.float64) * scale + o)
+    out["to"] = tuple(float(v) for v in np.asarray(cam_kw["to"], np.float64) * scale + o)
+    return out

@@ -4,6 +4,8 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- before librtx.so is loaded: torch brings its own HIP runtime (same soname), and a process
+#                that has already mapped the system one through librtx.so leaves torch without a visible GPU
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

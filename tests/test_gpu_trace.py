@@ -14,21 +14,21 @@ from conftest import pixel_centres
 pytestmark = pytest.mark.gpu
 
 
-def _rand_rays(pkg, n, seed, extent=1.2):
+def _rand_rays(pkg, n, seed, extent=1.2, centre=(0.0, 0.0, 0.0)):
     rs = np.random.RandomState(seed)
     rays = np.empty(n, pkg.RAY_DTYPE)
-    rays["o"] = rs.uniform(-extent, extent, (n, 3)).astype(np.float32)
+    rays["o"] = (rs.uniform(-extent, extent, (n, 3)) + np.asarray(centre)).astype(np.float32)
     d = rs.normal(size=(n, 3)).astype(np.float32)
     rays["d"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     return rays
 
 
-def _axis_rays(pkg, n, seed, extent=1.2, snap=None):
+def _axis_rays(pkg, n, seed, extent=1.2, snap=None, centre=(0.0, 0.0, 0.0)):
     """Directions with one or two exactly-zero components; origins optionally snapped to
     coordinates that occur in the scene (box faces)."""
     rs = np.random.RandomState(seed)
     rays = np.empty(n, pkg.RAY_DTYPE)
-    o = rs.uniform(-extent, extent, (n, 3)).astype(np.float32)
+    o = (rs.uniform(-extent, extent, (n, 3)) + np.asarray(centre)).astype(np.float32)
     if snap is not None:
         pick = rs.randint(0, len(snap), (n, 3))
         mask = rs.rand(n, 3) < 0.5
@@ -53,14 +53,18 @@ def _assert_hits_equal(got, want):
     assert np.all(got["t"][~hit] == np.finfo(np.float32).max)
 
 
-def _check_scene(pkg, lib, core, orc, scene, cam_kw, w=160, h=120, n_rand=40000, snap=None):
+def _check_scene(pkg, lib, core, orc, scene, cam_kw, w=160, h=120, n_rand=40000, snap=None, extent=1.2, centre=(0.0, 0.0, 0.0)):
+    """Primary rays, random rays and rays with zero direction components from a box of half-width
+    `extent` around `centre`; secondary rays from the hit points (origins on surfaces, and pushed off
+    them by EPSILON along the new direction the way the integrators do, RTBase/Renderer.h:513);
+    visibility segments between hit points and to random points."""
     core.upload_scene(scene)
     cam = pkg.look_at(lib, width=w, height=h, **cam_kw)
     core.set_camera(cam)
     osc = orc.scene(scene)
     osc.set_camera(cam)
-    rays = np.concatenate([osc.generate_rays(pixel_centres(w, h)), _rand_rays(pkg, n_rand, 1),
-                           _axis_rays(pkg, n_rand // 2, 2, snap=snap)])
+    rays = np.concatenate([osc.generate_rays(pixel_centres(w, h)), _rand_rays(pkg, n_rand, 1, extent, centre),
+                           _axis_rays(pkg, n_rand // 2, 2, extent, snap, centre)])
     want = osc.trace_closest(rays)
     got = core.trace_closest(rays)
     _assert_hits_equal(got, want)
@@ -70,9 +74,12 @@ def _check_scene(pkg, lib, core, orc, scene, cam_kw, w=160, h=120, n_rand=40000,
     sec = _rand_rays(pkg, int(hit.sum()), 3)
     sec["o"] = o2.astype(np.float32)
     _assert_hits_equal(core.trace_closest(sec), osc.trace_closest(sec))
+    sec["o"] = (o2.astype(np.float32) + sec["d"] * np.float32(0.001)).astype(np.float32)
+    _assert_hits_equal(core.trace_closest(sec), osc.trace_closest(sec))
     # visibility: hit point -> random point, hit point -> hit point
     rs = np.random.RandomState(4)
-    p2 = np.concatenate([rs.uniform(-1.5, 1.5, (len(o2) // 2, 3)).astype(np.float32), np.roll(o2, 7, axis=0)[: len(o2) - len(o2) // 2]])
+    p2 = np.concatenate([(rs.uniform(-1.25 * extent, 1.25 * extent, (len(o2) // 2, 3)) + np.asarray(centre)).astype(np.float32),
+                         np.roll(o2, 7, axis=0)[: len(o2) - len(o2) // 2]])
     seg = np.concatenate([o2.astype(np.float32), p2.astype(np.float32)], 1)
     assert np.array_equal(core.trace_visible(seg), osc.trace_visible(seg))
     osc.close()
