@@ -223,6 +223,19 @@ int rtx_trace_closest(rtx_ctx* ctx, const rtx_ray* rays, size_t n, rtx_hit* hits
 /* Same, rays and hits already in device memory (no copies, asynchronous on the stream). */
 int rtx_trace_closest_device(rtx_ctx* ctx, const rtx_ray* rays_dev, size_t n, rtx_hit* hits_dev);
 
+/* No counterpart in the reference: rtx_trace_closest_device for callers that cannot allocate device
+ * memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc). Same
+ * kernel, same results; the work counters and the global part of the traversal stacks live in a
+ * static device array of ~60 MiB that every GPU the library runs on holds until the process ends,
+ * instead of in buffers that grow on demand. It calls no allocating routine, and fails with
+ * RTX_ERR_INVALID beyond its fixed limits: n > RTX_NOALLOC_MAX_RAYS, or a scene whose tree can need
+ * more than RTX_NOALLOC_MAX_STACK traversal-stack entries per ray (max(3 * wide depth + 2, binary
+ * depth + 3); 32 for the 1 M-triangle soup, 38 for the mixed-material scene). All calls on one GPU
+ * share the array: calls that overlap on one GPU (two streams or two contexts) race. */
+#define RTX_NOALLOC_MAX_RAYS  0xF0000000ull
+#define RTX_NOALLOC_MAX_STACK 42
+int rtx_trace_closest_device_noalloc(rtx_ctx* ctx, const rtx_ray* rays_dev, size_t n, rtx_hit* hits_dev);
+
 /* Scene::visible, RTBase/Scene.h:170-178 → BVHTree::traverseVisible,
  * RTBase/Geometry.h:568-610, for n segments p1→p2 (6 floats each); visible[i] is 1 or 0. */
 int rtx_trace_visible(rtx_ctx* ctx, const float* p1p2, size_t n, uint8_t* visible);

@@ -165,6 +165,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "rtx_film_device": [vp, C.POINTER(vp), C.POINTER(sz)], "rtx_film_write": [vp, vp, C.c_int],
         "rtx_tile_samples_device": [vp, C.POINTER(vp), C.POINTER(sz)], "rtx_update_tile_samples": [vp],
         "rtx_trace_closest": [vp, vp, sz, vp], "rtx_trace_closest_device": [vp, vp, sz, vp],
+        "rtx_trace_closest_device_noalloc": [vp, vp, sz, vp],
         "rtx_trace_visible": [vp, vp, sz, vp], "rtx_trace_visible_device": [vp, vp, sz, vp],
         "rtx_generate_primary_rays_device": [vp, vp, vp, sz],
         "rtx_get_bvh": [vp, C.POINTER(C.c_uint32), vp, vp, vp],
@@ -315,6 +316,10 @@ class Core:
     # ray queries (device pointers, asynchronous)
     def trace_closest_device(self, rays_ptr: int, n: int, hits_ptr: int):
         self._check(self.lib.rtx_trace_closest_device(self.ctx, rays_ptr, n, hits_ptr))
+
+    def trace_closest_device_noalloc(self, rays_ptr: int, n: int, hits_ptr: int):
+        """The variant that allocates nothing (static scratch, fixed limits; see include/rtx.h)."""
+        self._check(self.lib.rtx_trace_closest_device_noalloc(self.ctx, rays_ptr, n, hits_ptr))
 
     def trace_visible_device(self, seg_ptr: int, n: int, vis_ptr: int):
         self._check(self.lib.rtx_trace_visible_device(self.ctx, seg_ptr, n, vis_ptr))

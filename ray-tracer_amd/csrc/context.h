@@ -62,6 +62,8 @@ struct rtx_ctx {
     rtx::DevBuf b_nodes4, b_nodes2, b_tris, b_tri_ids, b_shade, b_materials, b_texels, b_lights, b_env_texels, b_env_rows, b_env_cols, b_env_guide_rows, b_env_guide_cols;
     rtx::DevBuf b_spill;           // global part of the traversal stacks
     uint32_t spill_entries = 0;    // entries per lane in b_spill
+    uint32_t stack_need = 0;       // traversal-stack entries a ray of the current scene can need at most
+    void* na_scratch = nullptr;    // this device's copy of the static scratch of the no-allocation entry point
     rtx::DevBuf b_io_a, b_io_b;    // staging for the host-pointer entry points
     rtx::PinBuf pin_in, pin_out;
     rtx::DevBuf b_counters;

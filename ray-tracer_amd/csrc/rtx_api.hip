@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -42,6 +43,43 @@ int grid_for(size_t n) { return (int)std::min<size_t>((n + kBlock - 1) / kBlock,
 // kernels that fetch their work dynamically only need the workgroups that are resident at once
 int dyn_grid_for(const rtx_ctx* c, size_t n) { return (int)std::min<size_t>((n + kBlock - 1) / kBlock, (size_t)c->resident_blocks); }
 
+// ---- scratch of the entry point that allocates nothing (rtx_trace_closest_device_noalloc) -------------------
+// The closest-hit kernel needs two pieces of device memory beyond rays and hits: the work counters its waves draw
+// ray chunks from, and the part of the per-lane traversal stacks that does not fit in LDS. The other entry points
+// keep both in buffers that grow on demand (hipMalloc); this one keeps them in a file-scope device array of fixed
+// size, so that it can be called where allocation is not allowed. Every GPU the library runs on holds its own copy
+// (kNoAllocScratchBytes, ~60 MiB) until the process ends; all calls on a GPU share it, so calls that overlap on one
+// GPU (two streams, two contexts) race.
+constexpr int kNaBlocks = 1024;            // workgroups of a launch on the static scratch (4 per CU)
+constexpr int kNaSpillEntries = 30;        // stack entries per lane beyond the kLdsStack entries in LDS
+struct NoAllocScratch {
+    uint32_t work[kWorkSlotWords];                                     // zeroed by every call
+    uint2 spill[(size_t)kNaSpillEntries * kNaBlocks * kBlock];         // written before read, never cleared
+};
+constexpr size_t kNoAllocScratchBytes = sizeof(NoAllocScratch);
+static_assert(kLdsStack + kNaSpillEntries == RTX_NOALLOC_MAX_STACK, "include/rtx.h states the stack limit of the no-allocation entry point");
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+
+// `scratch` names the array for the compiler only; its address on a GPU comes from hipGetSymbolAddress with that
+// GPU current (each GPU has its own copy at its own address). Resolved once per device by rtx_create.
+constexpr int kMaxDevices = 64;
+void* g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mutex;
+
+int resolve_scratch(int device, void** out)
+{
+    if (device < 0 || device >= kMaxDevices) return fail(RTX_ERR_INVALID, "device %d beyond the %d the library keeps scratch for", device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));       // the caller has made `device` current
+        if (!p) return fail(RTX_ERR_HIP, "hipGetSymbolAddress returned a null address for the static scratch");
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return RTX_OK;
+}
+
 int ensure_spill(rtx_ctx* c)
 {
     size_t bytes = std::max<size_t>((size_t)c->spill_lanes * c->spill_entries * kMaxGridBlocks * kBlock * sizeof(uint2), 16);
@@ -77,6 +115,7 @@ static int create_resources(rtx_ctx* c, int device)
     c->device = device;
     c->variant = 1;
     if (const char* v = getenv("RTX_VARIANT")) c->variant = atoi(v);
+    { int rc = resolve_scratch(device, &c->na_scratch); if (rc) return rc; }
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     {
@@ -192,6 +231,7 @@ int rtx_upload_scene(rtx_ctx* c, const rtx_scene_desc* d)
     // level on the exact path; entries beyond the LDS part go to global memory
     uint32_t need = std::max(3u * h.bvh4.depth + 2u, h.bvh2.depth + 3u);
     // (sized for the shallowest LDS part any kernel variant uses)
+    c->stack_need = need;
     c->spill_entries = need > (uint32_t)kMinLdsStack ? need - kMinLdsStack : 0;
     if ((rc = ensure_spill(c))) return rc;
 
@@ -418,6 +458,27 @@ int rtx_trace_closest_device(rtx_ctx* c, const rtx_ray* rays, size_t n, rtx_hit*
                            (uint32_t)n, (const uint32_t*)nullptr, hits, c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), wc,
                            (unsigned long long*)nullptr);
     }
+    HIP_TRY(hipGetLastError());
+    c->stats.closest_rays += n;
+    return RTX_OK;
+}
+
+int rtx_trace_closest_device_noalloc(rtx_ctx* c, const rtx_ray* rays, size_t n, rtx_hit* hits)
+{
+    CTX_TRY(c);
+    if (!c->have_scene) return fail(RTX_ERR_STATE, "no scene uploaded");
+    if (n == 0) return RTX_OK;
+    if (!rays || !hits) return fail(RTX_ERR_INVALID, "null buffer");
+    if (n > RTX_NOALLOC_MAX_RAYS) return fail(RTX_ERR_INVALID, "%zu rays in one call, the no-allocation entry point takes at most %llu", n, (unsigned long long)RTX_NOALLOC_MAX_RAYS);
+    if (c->stack_need > (uint32_t)(kLdsStack + kNaSpillEntries))
+        return fail(RTX_ERR_INVALID, "the scene's tree needs %u traversal-stack entries per ray, the no-allocation entry point holds %d (RTX_NOALLOC_MAX_STACK)",
+                    c->stack_need, kLdsStack + kNaSpillEntries);
+    // from here on: the device address resolved at rtx_create, never the array's name
+    NoAllocScratch* s = (NoAllocScratch*)c->na_scratch;
+    HIP_TRY(hipMemsetAsync(s->work, 0, sizeof s->work, c->stream));
+    const int grid = std::min(dyn_grid_for(c, n), kNaBlocks);
+    hipLaunchKernelGGL(k_closest<false>, dim3(grid), dim3(kBlock), 0, c->stream, c->dscene, rays, (const uint32_t*)nullptr, (uint32_t)n,
+                       (const uint32_t*)nullptr, hits, s->spill, (uint32_t)(kNaBlocks * kBlock), s->work, (unsigned long long*)nullptr);
     HIP_TRY(hipGetLastError());
     c->stats.closest_rays += n;
     return RTX_OK;
