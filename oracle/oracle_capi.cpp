@@ -206,6 +206,23 @@ void orc_warp(int kind, float r1, float r2, float* out)
     put3(out, d); out[3] = pdf;
 }
 void orc_mt_stream(unsigned seed, int n, float* out) { MTSampler s(seed); for (int i = 0; i < n; i++) out[i] = s.next(); }
+// f(sampler->next(), sampler->next()) as the oracle spells it out (second parameter drawn first)
+void orc_warp_from_sampler(int kind, unsigned seed, float* out)
+{
+    MTSampler ms(seed); Sampler* s = &ms;
+    ORC_DRAW_R2_THEN_R1(s, r1, r2);
+    V3 d;
+    if (kind == 0) d = cosineSampleHemisphere(r1, r2);
+    else if (kind == 1) d = uniformSampleSphere(r1, r2);
+    else { float cosTheta = r1; float sinTheta = sqrtf(1.0f - cosTheta * cosTheta); float phi = (float)(2.0f * kPi * r2); d = v3(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta); }
+    put3(out, d);
+}
+// SphericalCoordinates, Core.h:557-572, as the Oren-Nayar restatement uses them
+void orc_spherical(float theta, float phi, const float* wi, float* out)
+{
+    put3(out, v3(cosf(phi) * sinf(theta), sinf(phi) * sinf(theta), cosf(theta)));
+    out[3] = BSDF::sphericalTheta(v3(wi[0], wi[1], wi[2])); out[4] = BSDF::sphericalPhi(v3(wi[0], wi[1], wi[2]));
+}
 
 // the counter sampler itself, for checking the device generator
 float orc_rng(uint32_t seed, uint32_t stream, uint32_t item, uint32_t sample, uint32_t dim) { return rtx_rng_float(rtx_rng_key(seed, stream, item, sample), dim); }

@@ -241,6 +241,8 @@ class RefCore:
         lib.ref_lum.argtypes = [_f]; lib.ref_lum.restype = C.c_float
         lib.ref_warp.argtypes = [C.c_int, C.c_float, C.c_float, _f]
         lib.ref_mt_stream.argtypes = [C.c_uint, C.c_int, _f]
+        lib.ref_warp_from_sampler.argtypes = [C.c_int, C.c_uint, _f]
+        lib.ref_spherical.argtypes = [C.c_float, C.c_float, _f, _f]
 
     @staticmethod
     def _a(v):
@@ -278,6 +280,13 @@ class RefCore:
 
     def mt_stream(self, seed, n):
         o = np.empty(n, np.float32); self.lib.ref_mt_stream(seed, n, o.ctypes.data_as(_f)); return o
+
+    def warp_from_sampler(self, kind, seed):
+        o = np.empty(3, np.float32); self.lib.ref_warp_from_sampler(kind, seed, o.ctypes.data_as(_f)); return o
+
+    def spherical(self, theta, phi, wi):
+        (a, pa) = self._a(wi); o = np.empty(5, np.float32)
+        self.lib.ref_spherical(theta, phi, pa, o.ctypes.data_as(_f)); return o
 
 
 class RefGem:

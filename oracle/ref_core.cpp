@@ -44,5 +44,25 @@ void ref_warp(int kind, float r1, float r2, float* out)
     out[0] = d.x; out[1] = d.y; out[2] = d.z; out[3] = pdf;
 }
 void ref_mt_stream(unsigned seed, int n, float* out) { MTRandom r(seed); for (int i = 0; i < n; i++) out[i] = r.next(); }
+// The call shape every BSDF and light of the reference uses, f(sampler->next(), sampler->next())
+// (RTBase/Materials.h:150,454,610; RTBase/Lights.h:78,96,123,131,324,398,409), through the virtual Sampler
+// interface on a real MTRandom: which draw lands in which parameter is the compiler's choice, and this
+// build (g++, the oracle of record) fixes it. kind as in ref_warp; out = dir(3).
+void ref_warp_from_sampler(int kind, unsigned seed, float* out)
+{
+    MTRandom r(seed); Sampler* sampler = &r; Vec3 d;
+    if (kind == 0) d = SamplingDistributions::cosineSampleHemisphere(sampler->next(), sampler->next());
+    else if (kind == 1) d = SamplingDistributions::uniformSampleSphere(sampler->next(), sampler->next());
+    else d = SamplingDistributions::uniformSampleHemisphere(sampler->next(), sampler->next());
+    out[0] = d.x; out[1] = d.y; out[2] = d.z;
+}
+// SphericalCoordinates, RTBase/Core.h:557-572 (used by OrenNayarBSDF): out = sphericalToWorld(theta, phi)(3),
+// sphericalTheta(wi), sphericalPhi(wi)
+void ref_spherical(float theta, float phi, const float* wi, float* out)
+{
+    Vec3 w = SphericalCoordinates::sphericalToWorld(theta, phi);
+    Vec3 v(wi[0], wi[1], wi[2]);
+    out[0] = w.x; out[1] = w.y; out[2] = w.z; out[3] = SphericalCoordinates::sphericalTheta(v); out[4] = SphericalCoordinates::sphericalPhi(v);
+}
 
 } // extern "C"

@@ -3,7 +3,9 @@ RTBase/Core.h + RTBase/Sampling.h (compiled into oracle/_ref/libref_core.so by
 oracle/Makefile, which needs /root/reference). Inputs are seeded; outputs are what the
 reference's own code returns: matrix inverse / lookAt / perspective / point and vector
 transforms, Frame::fromVector + toLocal + toWorld, the three sampling warps with their pdfs,
-Colour::Lum, and the first values of MTRandom for the seeds RayTracer uses.
+Colour::Lum, the first values of MTRandom for the seeds RayTracer uses, the warps called as
+f(sampler->next(), sampler->next()) on a real MTRandom (which draw lands in which parameter),
+and SphericalCoordinates.
 
 Run from the repository root:  python tests/golden/make_ref_core_vectors.py
 """
@@ -56,5 +58,15 @@ out["lum_in"] = cols
 out["lum"] = np.array([ref.lib.ref_lum(c.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_float))) for c in cols], np.float32)
 out["mt_seeds"] = np.array([48271, 96542, 1], np.uint32)
 out["mt_stream"] = np.array([ref.mt_stream(int(s), 64) for s in out["mt_seeds"]], np.float32)
+# f(sampler->next(), sampler->next()) on a real MTRandom under g++: the parameter each draw lands in
+out["wfs_seeds"] = np.array([48271, 96542, 1, 7, 123456789], np.uint32)
+for kind, name in ((0, "cosine_hemisphere"), (1, "uniform_sphere"), (2, "uniform_hemisphere")):
+    out["wfs_" + name] = np.array([ref.warp_from_sampler(kind, int(s)) for s in out["wfs_seeds"]], np.float32)
+# SphericalCoordinates (Core.h:557-572)
+sph = rs.uniform(0, 1, (64, 2)).astype(np.float32) * np.array([np.pi, 2 * np.pi], np.float32)
+swi = rs.normal(size=(64, 3)).astype(np.float32); swi /= np.linalg.norm(swi, axis=1, keepdims=True)
+swi[:4] = [[0, 0, 1], [0, 0, -1], [1, 0, 0], [-1, -1e-8, 0]]
+out["sph_in"], out["sph_wi"] = sph, swi.astype(np.float32)
+out["sph"] = np.array([ref.spherical(float(a), float(b), w) for (a, b), w in zip(sph, out["sph_wi"])], np.float32)
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_core_vectors.npz"), **out)
 print("wrote", {k: v.shape for k, v in out.items()})

@@ -86,6 +86,36 @@ def _check_scene(pkg, lib, core, orc, scene, cam_kw, w=160, h=120, n_rand=40000,
     return int(hit.sum())
 
 
+def test_reference_unit_test_rays_through_the_device_root_box_test(pkg, lib, core, orc):
+    """The reference's own known answers (UnitTests/test.cpp:3-34: AABB [1,3]^3; rays (0,0,0)->(1,1,1) hit,
+    (0,0,0)->(-1,-1,-1) miss, (2,2,2)->(1,1,1) hit) through rtx_trace_closest: the scene is that box as 12
+    triangles, so the scene's root box IS the test's AABB and the device's restatement of AABB::rayAABB decides
+    first. Directions are not normalised, as in the reference's test."""
+    import json
+    import os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "aabb_kat.json")))
+    lo, hi = (1.0, 1.0, 1.0), (3.0, 3.0, 3.0)
+    c = [(x, y, z) for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])]
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    pos = np.array([[c[a], c[b], c[d]] for a, b, d, e in quads] + [[c[a], c[d], c[e]] for a, b, d, e in quads], np.float32)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (12, 3, 1)); uv = np.zeros((12, 3, 2), np.float32)
+    sc = pkg.SceneArrays(pos, nrm, uv, np.zeros(12, np.uint32), [pkg.material()], [np.ones((1, 1, 3), np.float32)])
+    core.upload_scene(sc)
+    b = core.bvh()[0]
+    assert np.array_equal(b[0], [1, 1, 1, 3, 3, 3])
+    rays = np.empty(len(kat["cases"]), pkg.RAY_DTYPE)
+    rays["o"] = [k["origin"] for k in kat["cases"]]; rays["d"] = [k["dir"] for k in kat["cases"]]
+    hits = core.trace_closest(rays)
+    for k, h in zip(kat["cases"], hits):
+        assert (h["id"] != 0xFFFFFFFF) == k["hit"], k["name"]
+    assert hits["t"][0] == 1.0 and hits["t"][2] == 1.0      # the corners (1,1,1) and (3,3,3) along (1,1,1)
+    osc = orc.scene(sc)
+    _assert_hits_equal(hits, osc.trace_closest(rays))
+    more = _rand_rays(pkg, 20000, 13, extent=4.0, centre=(2, 2, 2))
+    _assert_hits_equal(core.trace_closest(more), osc.trace_closest(more))
+    osc.close()
+
+
 def test_closest_and_visible_soup(pkg, lib, core, orc, scenes):
     n = _check_scene(pkg, lib, core, orc, scenes.soup(100_000, seed=11), dict(frm=(0, 0, 3.5), to=(0, 0, 0), up=(0, 1, 0), fov=45.0))
     assert n > 10000

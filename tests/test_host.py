@@ -71,6 +71,20 @@ def test_camera_set_up_equals_oracle_bit_for_bit(pkg, lib, orc):
         assert a.afilm == b.afilm and (a.width, a.height) == (b.width, b.height) == (w, h)
 
 
+def test_product_camera_matrices_equal_real_reference_vectors_bit_for_bit(pkg, lib):
+    """rtx_camera_look_at (the product, not the oracle) against tests/golden/ref_core_vectors.npz, the outputs
+    of the real RTBase/Core.h: projection = Matrix::perspective, its inverse = Matrix::invert, view-to-world =
+    Matrix::lookAt(...).invert(), for the three cameras the vector file holds (16:9, fov 45)."""
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_core_vectors.npz"))
+    cams = (((0, 0, 3.5), (0, 0, 0)), ((0, 2.2, 7.5), (0, 0.8, 0)), ((3, 4, -5), (0.5, 0.25, 0.125)))
+    for k, (frm, to) in enumerate(cams):
+        persp = gold["matrices"][17 + 2 * k]
+        cam = pkg.look_at(lib, frm, to, (0, 1, 0), 45.0, 1920, 1080)
+        assert np.array_equal(np.array(cam.proj[:], np.float32), persp)
+        assert np.array_equal(np.array(cam.inv_proj[:], np.float32), gold["inverse"][17 + 2 * k])
+        assert np.array_equal(np.array(cam.camera[:], np.float32), gold["inverse"][16 + 2 * k])
+
+
 def test_counter_rng_known_values(orc):
     """The generator is a definition (include/rtx_rng.h); these values pin it."""
     got = [orc.lib.orc_rng(*a) for a in ((1, 0, 0, 1, 0), (1, 0, 0, 1, 1), (7, 1, 12345, 3, 9), (0xFFFFFFFF, 2, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF))]

@@ -249,3 +249,33 @@ def test_oracle_reproduces_frozen_path_vectors(pkg, lib, orc, scenes):
         assert np.allclose(r.film()[0], gold["pt_films"][k], rtol=1e-6, atol=1e-7), f"pass {k + 1}"
     assert np.array_equal(r.film()[2], gold["tile_targets"])
     r.close(); osc.close()
+
+
+def test_argument_order_and_spherical_coordinates_match_real_reference_vectors(orc, gold):
+    """`f(sampler->next(), sampler->next())` — the call shape of every BSDF / light sample in the
+    reference — leaves the order of the two draws to the compiler. The vectors were produced by the
+    real headers under g++ on a real MTRandom; the oracle's explicit "second parameter first" must
+    reproduce them bit for bit, and the opposite order must not (the test would be vacuous otherwise).
+    SphericalCoordinates (RTBase/Core.h:557-572) likewise."""
+    lib = orc.lib
+    lib.orc_warp_from_sampler.argtypes = [C.c_int, C.c_uint, _f]
+    lib.orc_warp.argtypes = [C.c_int, C.c_float, C.c_float, _f]
+    lib.orc_mt_stream.argtypes = [C.c_uint, C.c_int, _f]
+    for kind, name in ((0, "cosine_hemisphere"), (1, "uniform_sphere"), (2, "uniform_hemisphere")):
+        for seed, want in zip(gold["wfs_seeds"], gold["wfs_" + name]):
+            out = np.empty(3, np.float32)
+            lib.orc_warp_from_sampler(kind, int(seed), _fp(out))
+            assert np.array_equal(out, want), (name, seed)
+            draws = np.empty(2, np.float32)
+            lib.orc_mt_stream(int(seed), 2, _fp(draws))
+            first_is_r1 = np.empty(4, np.float32)
+            lib.orc_warp(kind, float(draws[0]), float(draws[1]), _fp(first_is_r1))
+            assert not np.array_equal(first_is_r1[:3], want), "draw order not observable for this seed"
+            first_is_r2 = np.empty(4, np.float32)
+            lib.orc_warp(kind, float(draws[1]), float(draws[0]), _fp(first_is_r2))
+            assert np.array_equal(first_is_r2[:3], want)
+    lib.orc_spherical.argtypes = [C.c_float, C.c_float, _f, _f]
+    for (theta, phi), wi, want in zip(gold["sph_in"], gold["sph_wi"], gold["sph"]):
+        out = np.empty(5, np.float32)
+        lib.orc_spherical(float(theta), float(phi), _fp(np.ascontiguousarray(wi)), _fp(out))
+        assert np.array_equal(out, want), (theta, phi, wi)
