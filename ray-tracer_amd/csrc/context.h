@@ -78,6 +78,7 @@ struct rtx_ctx {
     hipStream_t pipe_stream[rtx::kPipeline] = {};
     hipStream_t aux_stream[rtx::kPipeline] = {};       // per lane: shadow rays of depth d run beside the closest hits of depth d + 1
     hipEvent_t ev_shade[rtx::kPipeline] = {}, ev_shadow[rtx::kPipeline] = {};
+    int merge_shadow = 1;                              // path tracing: shadow rays of depth d share a launch with the closest hits of depth d + 1 (RTX_MERGE=0: separate launches)
     int overlap = 1;                                   // used when a call renders one pass at a time; RTX_OVERLAP=0 keeps a pass on one stream
     hipEvent_t pipe_film[rtx::kPipeline] = {}, pipe_done[rtx::kPipeline] = {}, ev_fork = nullptr, ev_tiles = nullptr;
 

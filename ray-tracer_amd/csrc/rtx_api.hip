@@ -140,6 +140,7 @@ static int create_resources(rtx_ctx* c, int device)
         HIP_TRY(hipEventCreateWithFlags(&c->ev_shadow[i], hipEventDisableTiming));
     }
     if (const char* v = getenv("RTX_OVERLAP")) c->overlap = atoi(v) != 0;
+    if (const char* v = getenv("RTX_MERGE")) c->merge_shadow = atoi(v) != 0;
     if (const char* v = getenv("RTX_PIPELINE")) c->pipeline = std::max(1, std::min(kPipeline, atoi(v)));
     HIP_TRY(c->b_counters.ensure(4 * (1 + 2) * kWorkSlotWords));   // instrumentation counters, then the work-counter slots of the closest-hit and visibility launches
     // RayTracer's defaults, RTBase/Settings.h:40-61

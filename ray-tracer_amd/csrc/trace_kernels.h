@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kBlock) void k_closest(DeviceScene sc, const rtx_ra
     ClosestPolicy pol{sc, rays, queue, hits};
     // the instrumented pass counts what one lane per ray visits, without helpers' speculative work
     __shared__ TailShare<kBlock> ts;
-    traverse_dyn<ClosestPolicy, false, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, COUNT ? 0 : kShare>(sc, stk, n_dev ? *n_dev : n_host, work_counter, pol, counters, &ts);
+    traverse_dyn<ClosestPolicy, kModeClosest, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, COUNT ? 0 : kShare>(sc, stk, n_dev ? *n_dev : n_host, work_counter, pol, counters, &ts);
 }
 
 // Schedules under test (A/B harness only)
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, W
     LaneStack<kBlock, LDS_N> stk; stk.init(lds, spill, spill_stride);
     ClosestPolicy pol{sc, rays, nullptr, hits};
     __shared__ TailShare<kBlock> ts;
-    traverse_dyn<ClosestPolicy, false, false, REFILL, kBlock, LDS_N, UNROLL, SCHED, SHARE>(sc, stk, n, work_counter, pol, nullptr, &ts);
+    traverse_dyn<ClosestPolicy, kModeClosest, false, REFILL, kBlock, LDS_N, UNROLL, SCHED, SHARE>(sc, stk, n, work_counter, pol, nullptr, &ts);
 }
 
 // ---- visibility: Scene::visible, RTBase/Scene.h:170-178 -> traverseVisible, Geometry.h:568-610 ----
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void k_visible(DeviceScene sc, const float*
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     VisiblePolicy pol{p1p2, visible};
     __shared__ TailShare<kBlock> ts;
-    traverse_dyn<VisiblePolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, n, work_counter, pol, nullptr, &ts);
+    traverse_dyn<VisiblePolicy, kModeAny, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, n, work_counter, pol, nullptr, &ts);
 }
 
 // Schedules under test (A/B harness only)
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void k_visible_ab(DeviceScene sc, const flo
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     VisiblePolicy pol{p1p2, visible};
     __shared__ TailShare<kBlock> ts;
-    traverse_dyn<VisiblePolicy, true, false, REFILL, kBlock, kLdsStack, UNROLL, SCHED, SHARE>(sc, stk, n, work_counter, pol, nullptr, &ts);
+    traverse_dyn<VisiblePolicy, kModeAny, false, REFILL, kBlock, kLdsStack, UNROLL, SCHED, SHARE>(sc, stk, n, work_counter, pol, nullptr, &ts);
 }
 
 // One segment, inside a kernel that loops over segments per lane (the VPL gather)

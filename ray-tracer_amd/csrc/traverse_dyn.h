@@ -14,8 +14,11 @@
 // the order of independent steps differ.
 //
 // A Policy supplies the items and consumes the results:
-//   bool  fetch(uint32_t k, float o[3], float d[3], float& maxT)   load item k (k < n)
+//   void  fetch(uint32_t k, float o[3], float d[3], float& maxT)   load item k (k < n)
 //   void  retire(uint32_t k, const HitRec& best, bool reached)     reached == false: the ray missed the root box
+// MODE selects what a ray asks for: kModeClosest (closest hit), kModeAny (visibility: any hit with t <= maxT ends
+// the ray) or kModeMixed, where every item says which of the two it is (fetch takes a further `bool& any`): one
+// launch then serves the shadow rays of one path depth and the closest-hit rays of the next.
 #pragma once
 
 #include "traverse.h"
@@ -74,7 +77,9 @@ __device__ __forceinline__ uint32_t nth_set_bit(unsigned long long m, uint32_t n
     return pos;
 }
 
-template <class Policy, bool ANY, bool COUNT, int REFILL, int BLOCK, int LDS_N, int TRI_UNROLL, int SCHED, int SHARE = 0>
+constexpr int kModeClosest = 0, kModeAny = 1, kModeMixed = 2;
+
+template <class Policy, int MODE, bool COUNT, int REFILL, int BLOCK, int LDS_N, int TRI_UNROLL, int SCHED, int SHARE = 0>
 __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BLOCK, LDS_N>& stk, uint32_t n, uint32_t* work,
                                              Policy& pol, unsigned long long* counters, TailShare<BLOCK>* ts = nullptr)
 {
@@ -88,6 +93,8 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
     uint32_t wave_iters[3] = {0, 0, 0};   // COUNT only: inner-loop, triangle-loop and outer-loop trips of this lane
     uint32_t cur = kDone, item = kNone;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, bound = FLT_MAX, maxT = 0;
+    bool any_lane = MODE == kModeAny;      // kModeMixed: set per item
+#define RTX_IS_ANY (MODE == kModeMixed ? any_lane : MODE == kModeAny)
     HitRec best; best.t = FLT_MAX; best.u = best.v = 0; best.pos = kNone;
     // Work distribution. Items are handed out in chunks of 64. Chunk g belongs to counter
     // g % kWorkSegments, and counter s hands out its chunks in ascending order, so that the
@@ -108,7 +115,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
                     if (best.pos != kNone) atomicMin(&ts->key[own], pack_hit(best));
                     atomicSub(&ts->pending[own], 1u);
                     item = kNone;
-                } else if (ANY && cur != kDone && (uint32_t)lds_read(&ts->key[own]) != kNone) {
+                } else if (RTX_IS_ANY && cur != kDone && (uint32_t)lds_read(&ts->key[own]) != kNone) {
                     cur = kDone; stk.sp = 0;     // somebody found an occluder for this ray
                 }
             }
@@ -122,7 +129,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
                     const unsigned long long kk = lds_read(&ts->key[threadIdx.x]);
                     if (ready && kk < pack_hit(best)) {
                         best.pos = (uint32_t)kk; best.t = __uint_as_float((uint32_t)(kk >> 32));
-                        if (!ANY) { float t; tri_test(sc.tris[best.pos], ox, oy, oz, dx, dy, dz, t, best.u, best.v); }
+                        if (!RTX_IS_ANY) { float t; tri_test(sc.tris[best.pos], ox, oy, oz, dx, dy, dz, t, best.u, best.v); }
                     }
                 }
             }
@@ -158,18 +165,22 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
             if (cur == kDone && item == kNone && rank < take) {
                 const uint32_t k = loc_next + rank;
                 float o[3], d[3];
-                pol.fetch(k, o, d, maxT);
+                if constexpr (MODE == kModeMixed) pol.fetch(k, o, d, maxT, any_lane); else pol.fetch(k, o, d, maxT);
                 ox = o[0]; oy = o[1]; oz = o[2]; dx = d[0]; dy = d[1]; dz = d[2];
                 ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;                                    // Ray::init, Geometry.h:25
                 best.t = FLT_MAX; best.u = best.v = 0; best.pos = kNone; stk.sp = 0;
-                bound = ANY ? (maxT + (fabsf(maxT) * kCullRel + kCullAbs)) : FLT_MAX;
+                bound = RTX_IS_ANY ? (maxT + (fabsf(maxT) * kCullRel + kCullAbs)) : FLT_MAX;
                 // root box first (Geometry.h:509 / :571)
                 if (slab_reference(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ox, oy, oz, ix, iy, iz)) {
                     const bool finite = (fabsf(ix) <= FLT_MAX) && (fabsf(iy) <= FLT_MAX) && (fabsf(iz) <= FLT_MAX);
                     if (finite) {
                         cur = 0; item = k; mark = cnt;
                     }
-                    else { traverse_exact<ANY, BLOCK, LDS_N>(sc, stk, ox, oy, oz, dx, dy, dz, ix, iy, iz, maxT, best); pol.retire(k, best, true); }
+                    else {
+                        if (RTX_IS_ANY) traverse_exact<true, BLOCK, LDS_N>(sc, stk, ox, oy, oz, dx, dy, dz, ix, iy, iz, maxT, best);
+                        else traverse_exact<false, BLOCK, LDS_N>(sc, stk, ox, oy, oz, dx, dy, dz, ix, iy, iz, maxT, best);
+                        pol.retire(k, best, true);
+                    }
                 } else pol.retire(k, best, false);
             }
             loc_next += take;
@@ -194,6 +205,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
                     const float sdx = __shfl(dx, (int)dl, 64), sdy = __shfl(dy, (int)dl, 64), sdz = __shfl(dz, (int)dl, 64);
                     const float six = __shfl(ix, (int)dl, 64), siy = __shfl(iy, (int)dl, 64), siz = __shfl(iz, (int)dl, 64);
                     const float smax = __shfl(maxT, (int)dl, 64), sbound = __shfl(bound, (int)dl, 64);
+                    const bool sany = MODE == kModeMixed ? (__shfl((int)any_lane, (int)dl, 64) != 0) : (MODE == kModeAny);
                     const bool is_free = (cur == kDone && item == kNone);
                     if (cur != kDone && stk.sp > 0) {
                         const uint32_t rd = (uint32_t)__popcll(donM & below);
@@ -201,7 +213,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
                         stk.sp -= (int)min(offered, (uint32_t)stk.sp);
                     } else if (is_free && (int)q < d_sp) {
                         const uint2 e = stk.peek_other(d_sp - 1 - (int)q, (int)dl - (int)lane);
-                        ox = sox; oy = soy; oz = soz; dx = sdx; dy = sdy; dz = sdz; ix = six; iy = siy; iz = siz; maxT = smax; bound = sbound;
+                        ox = sox; oy = soy; oz = soz; dx = sdx; dy = sdy; dz = sdz; ix = six; iy = siy; iz = siz; maxT = smax; bound = sbound; any_lane = sany;
                         best.t = FLT_MAX; best.u = best.v = 0; best.pos = kNone; stk.sp = 0;
                         const uint32_t own = d_item >= kHelper ? (d_item & 63u) : dl;
                         item = kHelper | own;
@@ -216,15 +228,15 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
         if (COUNT) wave_iters[2]++;
         // every lane descends until it holds a leaf
         if (SCHED == 0) {
-            while (!(cur & kLeafBit) && cur != kDone) { if (COUNT) wave_iters[0]++; cur = step_inner<COUNT, BLOCK, LDS_N, ANY ? 1 : 0>(sc, stk, cur, ox, oy, oz, ix, iy, iz, bound, &cnt); }
+            while (!(cur & kLeafBit) && cur != kDone) { if (COUNT) wave_iters[0]++; cur = step_inner<COUNT, BLOCK, LDS_N, MODE == kModeAny ? 1 : 0>(sc, stk, cur, ox, oy, oz, ix, iy, iz, bound, &cnt); }
         } else if (SCHED == 1) {
-            if (!(cur & kLeafBit) && cur != kDone) { if (COUNT) wave_iters[0]++; cur = step_inner<COUNT, BLOCK, LDS_N, ANY ? 1 : 0>(sc, stk, cur, ox, oy, oz, ix, iy, iz, bound, &cnt); }
+            if (!(cur & kLeafBit) && cur != kDone) { if (COUNT) wave_iters[0]++; cur = step_inner<COUNT, BLOCK, LDS_N, MODE == kModeAny ? 1 : 0>(sc, stk, cur, ox, oy, oz, ix, iy, iz, bound, &cnt); }
         } else {
             // descend until SCHED lanes hold a leaf (or nobody has an inner node left)
             for (;;) {
                 const bool inner = !(cur & kLeafBit) && cur != kDone;
                 if (!__any(inner)) break;
-                if (inner) { if (COUNT) wave_iters[0]++; cur = step_inner<COUNT, BLOCK, LDS_N, ANY ? 1 : 0>(sc, stk, cur, ox, oy, oz, ix, iy, iz, bound, &cnt); }
+                if (inner) { if (COUNT) wave_iters[0]++; cur = step_inner<COUNT, BLOCK, LDS_N, MODE == kModeAny ? 1 : 0>(sc, stk, cur, ox, oy, oz, ix, iy, iz, bound, &cnt); }
                 if (__popcll(__ballot((cur & kLeafBit) != 0)) >= SCHED) break;
             }
         }
@@ -252,18 +264,18 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
                         if (COUNT) cnt.tris++;
                         float t, u, v;
                         if (tri_test(T[j], ox, oy, oz, dx, dy, dz, t, u, v)) {
-                            if (ANY) { if (t <= maxT && !occluded) { occluded = true; best.pos = first + k + (uint32_t)j; best.t = t; } }
+                            if (RTX_IS_ANY) { if (t <= maxT && !occluded) { occluded = true; best.pos = first + k + (uint32_t)j; best.t = t; } }
                             else consider(best, t, u, v, first + k + (uint32_t)j);
                         }
                     }
                 }
-                if (ANY && occluded) break;
+                if (RTX_IS_ANY && occluded) break;
             }
-            if (ANY && occluded) {
+            if (RTX_IS_ANY && occluded) {
                 cur = kDone;
                 if constexpr (SHARE) { if (tail) { atomicMin(&ts->key[wave0 + (item >= kHelper ? (item & 63u) : lane)], pack_hit(best)); stk.sp = 0; } }
             } else {
-                if (!ANY) {
+                if (!RTX_IS_ANY) {
                     float bt = best.t;
                     if constexpr (SHARE) {
                         if (tail) {
@@ -280,6 +292,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
             }
         }
     }
+#undef RTX_IS_ANY
     if (COUNT) {
         atomicAdd(&counters[0], (unsigned long long)cnt.nodes); atomicAdd(&counters[1], (unsigned long long)cnt.tris);
         // wave-level trip counts: the maximum over the lanes of a wave is what the wave executed

@@ -327,7 +327,42 @@ __global__ __launch_bounds__(kBlock) void k_shadow_accumulate(WfPtrs w, DeviceSc
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     ShadowAccumulatePolicy pol{w};
     __shared__ TailShare<kBlock> ts;
-    traverse_dyn<ShadowAccumulatePolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, nullptr, &ts);
+    traverse_dyn<ShadowAccumulatePolicy, kModeAny, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, nullptr, &ts);
+}
+
+// The shadow rays of depth d - 1 and the closest-hit rays of depth d in ONE launch: neither depends on the other
+// (both come out of the shade kernel of depth d - 1), late depths hold few rays, and a traversal launch lasts at
+// least as long as its slowest ray, so one launch for both halves the number of such floors per pass. Items
+// [0, n_closest) are the live paths of `queue`, items from n_closest on the shadow segments.
+struct PtMixedPolicy {
+    const DeviceScene& sc; const WfPtrs& w; const uint32_t* queue; uint32_t n_closest;
+    __device__ __forceinline__ void fetch(uint32_t k, float o[3], float d[3], float& maxT, bool& any) const
+    {
+        if (k < n_closest) {
+            const rtx_ray r = w.ray[queue[k]];
+            o[0] = r.o[0]; o[1] = r.o[1]; o[2] = r.o[2]; d[0] = r.d[0]; d[1] = r.d[1]; d[2] = r.d[2]; maxT = 0.0f; any = false;
+        } else { segment_to_ray(w.sseg + 6 * (size_t)(k - n_closest), o, d, maxT); any = true; }
+    }
+    __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool reached) const
+    {
+        if (k < n_closest) w.hit[queue[k]] = make_hit(sc, best);
+        else if (reached && best.pos == 0xFFFFFFFFu) {
+            const uint32_t j = k - n_closest, slot = w.spath[j];
+            C3 L = ldc(w.L + 3 * slot) + ldc(w.sval + 3 * (size_t)j);
+            st3(w.L + 3 * slot, L);
+        }
+    }
+};
+// (the per-item flag costs registers: held to the 96 that keep five waves per SIMD like the other traversal kernels; +3 % on a 1080p pass)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_pt_trace_mixed(WfPtrs w, DeviceScene sc, uint32_t depth, const uint32_t* __restrict__ queue, uint32_t work_index,
+                                                           uint2* spill, uint32_t spill_stride)
+{
+    __shared__ unsigned long long lds[kBlock * kLdsStack];
+    LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
+    const uint32_t n_closest = w.cnt[depth], n_shadow = w.cnt[kShadowCounterBase + depth - 1];
+    PtMixedPolicy pol{sc, w, queue, n_closest};
+    __shared__ TailShare<kBlock> ts;
+    traverse_dyn<PtMixedPolicy, kModeMixed, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, n_closest + n_shadow, w.cnt + work_index, pol, nullptr, &ts);
 }
 
 // film->splat(px, py, col) for every sample of the pass, Renderer.h:745
@@ -537,7 +572,7 @@ __global__ __launch_bounds__(kBlock) void k_lt_splat(WfPtrs w, DeviceScene sc, u
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     SplatPolicy pol{w, filter};
     __shared__ TailShare<kBlock> ts;
-    traverse_dyn<SplatPolicy, true, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, nullptr, &ts);
+    traverse_dyn<SplatPolicy, kModeAny, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, nullptr, &ts);
 }
 
 // ---- instant radiosity: RTBase/Renderer.h:124-302 -------------------------------------------
@@ -801,6 +836,19 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, w, pp);
         hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
         uint32_t* qin = w.qa; uint32_t* qout = w.qb;
+        if (c->merge_shadow) {
+            // closest(0), shade(0), then per depth ONE traversal launch for the shadow rays of depth d - 1 and the
+            // closest hits of depth d, shade(d); the shadow rays of the last depth go alone
+            for (uint32_t d = 0; d <= st.max_bounces; d++) {
+                pp.depth = d;
+                if (d == 0) closest(qin, 0);
+                else hipLaunchKernelGGL(k_pt_trace_mixed, gridT, blk, 0, s, w, c->dscene, d, (const uint32_t*)qin, (uint32_t)(kClosestWorkBase + d * kWorkSlotWords), spill, sstride);
+                hipLaunchKernelGGL(k_pt_shade, gridQ, blk, 0, s, w, c->dscene, pp, (const uint32_t*)qin, qout);
+                std::swap(qin, qout);
+            }
+            hipLaunchKernelGGL(k_shadow_accumulate, gridT, blk, 0, s, w, c->dscene, (uint32_t)(kShadowCounterBase + st.max_bounces),
+                               (uint32_t)(kShadowWorkBase + st.max_bounces * kWorkSlotWords), spill, sstride);
+        } else {
         // The shadow rays of depth d and the closest hits of depth d + 1 do not depend on each other:
         // the former run on the lane's second stream. The shade kernel of depth d + 1 waits for them
         // (it adds to the same radiance slots and refills the shadow queue). Worth 16 % when one pass runs
@@ -818,6 +866,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
             std::swap(qin, qout);
         }
         if (overlap && hipStreamWaitEvent(s, c->ev_shadow[lane], 0) != hipSuccess) return RTX_ERR_HIP;
+        }
         if (film_wait && hipStreamWaitEvent(s, film_wait, 0) != hipSuccess) return RTX_ERR_HIP;
         launch_film_accumulate(w, (int)st.filter, gridP, blk, s);
         c->stats.samples += (uint64_t)w.W * w.H;

@@ -6,8 +6,9 @@ same order; with the box filter the film after one pass IS the radiance of sampl
 Intersection is bit-exact; shading goes through sinf/cosf/powf/acosf/atan2f, whose device
 and glibc versions differ in the last bits, and the reference's recursion sums the bounce
 terms in the opposite order to the wavefront loop. Tolerance (stated per test): relative
-1e-4 on each channel against max(|oracle|, 1e-3), with at most 0.5 % of pixels allowed to
-differ more (a last-bit difference can flip a Russian-roulette / Fresnel / CDF decision).
+1e-4 on each channel against max(|oracle|, 1e-3), with at most 0.1 % of pixels allowed to
+differ more (a last-bit difference can flip a Russian-roulette / Fresnel / CDF decision; measured on
+the MI355X: at most 0.03 % of the pixels of any test here, 0 for most).
 
 Converged parity: many samples against the oracle run with the reference's own
 per-thread MT19937 streams (independent randomness) — a statistical test.
@@ -18,7 +19,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 REL_TOL = 1e-4
-OUTLIER_FRACTION = 0.005
+OUTLIER_FRACTION = 0.001
 
 
 def _setup(pkg, lib, core, orc, scene, cam_kw, w, h, **settings):
@@ -43,6 +44,7 @@ def _assert_films_match(got, want, what, frac=OUTLIER_FRACTION):
     assert np.isfinite(got).all() == np.isfinite(want).all()
     g, w = np.nan_to_num(got, posinf=0, neginf=0), np.nan_to_num(want, posinf=0, neginf=0)
     f, err = _outliers(g, w)
+    print(f"{what}: {f:.4%} of pixels beyond rel {REL_TOL} (allowed {frac:.2%})")
     assert f <= frac, f"{what}: {f:.4%} of pixels beyond rel {REL_TOL} (median err {np.median(err):.2e})"
 
 
@@ -68,7 +70,7 @@ def test_path_trace_per_sample_parity_env_mis(pkg, lib, core, orc, scenes):
         r = osc.renderer(st, threads=8, counter_rng=True)
         core.render_passes(2); r.render_passes(2)
         g, _, _ = core.film(); o, _, _ = r.film()
-        _assert_films_match(g, o, f"env scene mis={mis}", frac=0.01)
+        _assert_films_match(g, o, f"env scene mis={mis}")
         assert g.mean() > 0.01
 
 
@@ -88,7 +90,7 @@ def test_env_sampling_tables_of_any_shape(pkg, lib, core, orc, scenes, case):
     r = osc.renderer(st, threads=8, counter_rng=True)
     core.render_passes(2); r.render_passes(2)
     g, _, _ = core.film(); o, _, _ = r.film()
-    _assert_films_match(g, o, f"env {case}", frac=0.01)
+    _assert_films_match(g, o, f"env {case}")
     assert np.nan_to_num(g).mean() > 0.01
 
 
@@ -120,8 +122,9 @@ def test_light_trace_parity(pkg, lib, core, orc, scenes):
     assert spp == ospp == 4 and o.sum() > 0
     scale = np.abs(o).max()
     bad = (np.abs(g - o) > 1e-4 * scale + 1e-4 * np.abs(o)).any(-1)
-    assert bad.mean() <= 0.01, f"{bad.mean():.4%} of pixels differ"
-    assert abs(g.sum() - o.sum()) <= 2e-3 * abs(o.sum())
+    print(f"light trace: {bad.mean():.4%} of pixels differ, film sums {g.sum():.6g} vs {o.sum():.6g}")
+    assert bad.mean() <= 0.001, f"{bad.mean():.4%} of pixels differ"       # measured: none
+    assert abs(g.sum() - o.sum()) <= 1e-4 * abs(o.sum())
 
 
 def test_instant_radiosity_parity(pkg, lib, core, orc, scenes):
@@ -130,7 +133,7 @@ def test_instant_radiosity_parity(pkg, lib, core, orc, scenes):
     r = osc.renderer(st, threads=4, counter_rng=True)
     core.render_passes(2); r.render_passes(2)
     assert len(r.vpls()) >= 12
-    _assert_films_match(core.film()[0], r.film()[0], "instant radiosity", frac=0.02)
+    _assert_films_match(core.film()[0], r.film()[0], "instant radiosity")         # measured: no pixel beyond the tolerance
 
 
 def test_gaussian_and_mitchell_filters(pkg, lib, core, orc, scenes):
@@ -163,7 +166,7 @@ def test_adaptive_sampling_tile_targets(pkg, lib, core, orc, scenes):
     assert (np.abs(gt.astype(np.int64) - ot.astype(np.int64)) <= 1).all() and (gt != ot).mean() <= 0.1
     assert gt.min() >= 4 and gt.max() <= 24 and len(np.unique(gt)) > 3
     same = np.repeat(np.repeat((gt == ot).reshape(5, 7), 16, 0), 16, 1)[:70, :100]
-    _assert_films_match(g * same[..., None], o * same[..., None], "adaptive film", frac=0.01)
+    _assert_films_match(g * same[..., None], o * same[..., None], "adaptive film", frac=0.002)
 
 
 def test_tile_sharding_is_bit_identical_and_spp_split_sums(pkg, lib, core, orc, scenes):
@@ -189,30 +192,43 @@ def test_tile_sharding_is_bit_identical_and_spp_split_sums(pkg, lib, core, orc, 
     assert np.allclose(acc, full, rtol=1e-5, atol=1e-6)
 
 
-def test_converged_radiance_vs_reference_streams(pkg, lib, core, orc, scenes):
-    """Statistical parity at high spp against the oracle driven by the reference's own
-    per-thread MT19937 streams (independent randomness). The noise floor is measured, not
-    guessed: two GPU renders with different seeds give the RMSE that pure Monte-Carlo noise
-    produces at this spp; the GPU-vs-oracle RMSE (8x8-binned, radiance clipped at 4) must
-    stay within 1.5x that floor + 0.5 % of the mean, and the mean radiance within 1.5 %."""
-    spp = 768
-
-    def binned(film):
-        return np.clip(film / spp, 0, 4).reshape(8, 8, 8, 8, 3).mean((1, 3))
-
-    scene, cam_kw = scenes.cornell_box("mixed"), scenes.cornell_camera()
+@pytest.mark.parametrize("which", ["cornell", "env_mis"])
+def test_converged_radiance_per_pixel_vs_reference_streams(pkg, lib, core, orc, scenes, which):
+    """Statistical parity at high spp, PER PIXEL, against the oracle driven by the reference's own
+    per-thread MT19937 streams (independent randomness), on the Cornell stand-in and on the
+    environment-lit mixed-material scene with MIS. The noise floor is measured, not guessed: two GPU
+    renders with different seeds differ per pixel by pure Monte-Carlo noise of this spp; an unbiased
+    independent estimate differs from either by the same amount in expectation. Tolerance: per-pixel
+    RMSE (radiance clipped at 4, no binning) GPU-vs-oracle <= 1.15 x the GPU-vs-GPU RMSE + 0.2 % of
+    the mean radiance; mean radiance within 1 %; and the pixels whose GPU-vs-oracle difference exceeds
+    five times the noise floor (local, 3x3-smoothed; itself a noisy estimate on heavy-tailed radiance)
+    stay below 2 % (measured: 0.9 % Cornell, 0.3 % environment scene; RMSE ratios 1.05 and 1.02)."""
+    spp = 1024
+    if which == "cornell":
+        scene, cam_kw, w, h = scenes.cornell_box("mixed"), scenes.cornell_camera(), 96, 96
+    else:
+        scene, cam_kw, w, h = scenes.mixed_scene(32, (256, 128)), scenes.mixed_camera(), 128, 72
     imgs = []
     for seed in (21, 22):
-        st, osc = _setup(pkg, lib, core, orc, scene, cam_kw, 64, 64, total_spp=spp, seed=seed)
+        st, osc = _setup(pkg, lib, core, orc, scene, cam_kw, w, h, total_spp=spp, seed=seed, use_mis=1)
         core.render_passes(spp)
-        imgs.append(binned(core.film()[0]))
+        imgs.append(np.clip(core.film()[0] / spp, 0, 4))
     r = osc.renderer(st, threads=16, counter_rng=False)
     r.render_passes(spp)
-    o = binned(r.film()[0])
+    o = np.clip(r.film()[0] / spp, 0, 4)
     rmse = lambda a, b: float(np.sqrt(((a - b) ** 2).mean()))
-    floor = rmse(imgs[0], imgs[1])
-    assert rmse(imgs[0], o) <= 1.5 * floor + 0.005 * o.mean(), (rmse(imgs[0], o), floor, o.mean())
-    assert abs(imgs[0].mean() - o.mean()) <= 0.015 * o.mean()
+    floor, got = rmse(imgs[0], imgs[1]), rmse(imgs[0], o)
+    print(f"converged {which}: per-pixel rmse gpu-vs-oracle {got:.5f}, gpu-vs-gpu {floor:.5f}, ratio {got / floor:.3f}, mean {o.mean():.4f}")
+    assert got <= 1.15 * floor + 0.002 * o.mean(), (got, floor, o.mean())
+    assert abs(imgs[0].mean() - o.mean()) <= 0.01 * o.mean()
+    # local noise floor: 3x3 box mean of the squared GPU-vs-GPU difference
+    d2 = ((imgs[0] - imgs[1]) ** 2).sum(-1)
+    pad = np.pad(d2, 1, mode="edge")
+    local = sum(pad[i:i + h, j:j + w] for i in range(3) for j in range(3)) / 9.0
+    e2 = ((imgs[0] - o) ** 2).sum(-1)
+    far = e2 > 25.0 * local + (0.01 * o.mean()) ** 2
+    print(f"converged {which}: {far.mean():.4%} of pixels beyond 5x the local noise floor")
+    assert far.mean() <= 0.02
 
 
 def test_create_aov_planes(pkg, lib, core, orc, scenes):
@@ -265,11 +281,13 @@ def test_device_matches_frozen_path_vectors(pkg, lib, core, scenes):
     for k in range(3):
         core.render_passes(1)
         g = core.film()[0]
-        _assert_films_match(g - prev, gold["pt_films"][k] - (gold["pt_films"][k - 1] if k else 0), f"frozen sample {k + 1}", frac=0.01)
+        _assert_films_match(g - prev, gold["pt_films"][k] - (gold["pt_films"][k - 1] if k else 0), f"frozen sample {k + 1}")
         prev = g
     # tile targets come from a film that may differ in the last bits: allow one sample of slack
     assert np.abs(core.film()[2].astype(np.int64) - gold["tile_targets"].astype(np.int64)).max() <= 1
     core.set_settings(pkg.make_settings(algorithm=pkg.AL_LIGHT_TRACE, total_spp=1, seed=11))
     core.clear(); core.render_passes(1)
     lt = core.film()[0]
-    assert abs(float(lt.sum()) - float(gold["lt_film"].sum())) <= 0.02 * float(gold["lt_film"].sum())
+    scale = np.abs(gold["lt_film"]).max()
+    assert ((np.abs(lt - gold["lt_film"]) > 1e-4 * scale + 1e-4 * np.abs(gold["lt_film"])).any(-1)).mean() <= 0.001
+    assert abs(float(lt.sum()) - float(gold["lt_film"].sum())) <= 1e-4 * float(gold["lt_film"].sum())
