@@ -13,7 +13,6 @@ data-path collective); value = rays of all ranks / max-over-ranks time.
 from __future__ import annotations
 
 import argparse
-import ctypes
 import importlib
 import json
 import os
@@ -25,7 +24,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
 NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 128, 36, 24, 20
 
 
@@ -39,6 +37,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pathtrace", action="store_true")
+    ap.add_argument("--no-big", action="store_true", help="skip the 10 M-triangle 4K closest-hit measurement")
+    ap.add_argument("--only", default="", choices=["", "headline", "extras", "pathtrace"], help="profiling: run the headline leg plus only this part")
     ap.add_argument("--pt-spp", type=int, default=64, help="passes of the path-trace side measurement")
     ap.add_argument("--variants", default="", help="A/B: comma list of RTX_VARIANT values, interleaved rounds in one process")
     ap.add_argument("--ab-scene", default="soup", choices=["soup", "mixed"])
@@ -151,58 +151,135 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        core.trace_closest_device(rays.data_ptr(), n, hits.data_ptr())
-    barrier()
-    t0 = time.perf_counter()
-    core.timer_begin()
-    for _ in range(args.steps):
-        core.trace_closest_device(rays.data_ptr(), n, hits.data_ptr())
-    kernel_ms = core.timer_end() / max(args.steps, 1)     # HIP events on the launch stream
-    barrier()
-    elapsed = time.perf_counter() - t0
+    prof = load_profiles()
+    t_elapsed, kernel_ms = time_closest(core, rays, hits, n, args.steps, args.warmup, barrier)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([t_elapsed], dtype=torch.float64, device=dev)
         all_reduce(t, dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    mrays = world * n * args.steps / elapsed / 1e6
+        t_elapsed = float(t.item())
+    mrays = world * n * args.steps / t_elapsed / 1e6
 
-    # algorithmic traffic of the layout for these rays (instrumented pass, untimed)
-    nodes, tris = core.count_closest_work(rays.data_ptr(), n)
-    bytes_per_launch = n * (RAY_BYTES + HIT_BYTES) + nodes * NODE_BYTES + tris * TRI_BYTES
-    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("k_closest_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-
+    # algorithmic work of the layout for these rays (instrumented pass, untimed)
+    nodes, tris, groups = core.count_closest_work(rays.data_ptr(), n)
     out = {
         "metric": "closest-hit Mrays/s (1M-triangle soup, 1920x1080 primary rays, hit ids bit-exact vs reference BVH)",
         "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(t_elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[1]: {scene.n_triangles}-triangle soup (seed 12345), {args.width}x{args.height} pixel-centre primary rays per GPU, closest hit",
                    "rays_per_step_per_gpu": n, "bvh4_nodes": core.stats().bvh4_nodes},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "k_closest", "kernel_ms": round(kernel_ms, 4),
-                     "algorithmic_bytes_per_ray": round(bytes_per_launch / n, 1),
-                     "nodes_per_ray": round(nodes / n, 2), "tris_per_ray": round(tris / n, 2)},
+        "roofline": roofline(n, nodes, tris, groups, kernel_ms, prof, "headline"),
     }
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    only = args.only
+    if rank == 0 and world == 1 and only in ("", "extras"):
+        # the same kernel where the tail of a launch weighs less (4x the rays per launch) ...
+        out["closest_soup_4k"] = closest_extra(pkg, lib, core, torch, dev, None, (0, 0, 3.5), (0, 0, 0), 45.0, 3840, 2160, args, prof, None, barrier)
+        if not args.no_big:
+            # ... and where tree and triangles (1.6 GB) no longer fit the caches: benchmark configuration 3's scene
+            out["closest_terrain10m_4k"] = closest_extra(pkg, lib, core, torch, dev, scenes.terrain(2236), scenes.terrain_camera()["frm"], scenes.terrain_camera()["to"], 45.0,
+                                                         3840, 2160, args, prof, "big", barrier)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and only == "":
         out["cpu_baseline"] = cpu_baseline(pkg, scene, cam, args)
-    if not args.no_pathtrace:
-        pt = pathtrace_side(pkg, scenes, lib, core, torch, dist, world, rank, dev, args, all_reduce)
+    if not args.no_pathtrace and only in ("", "pathtrace"):
+        pt = pathtrace_side(pkg, scenes, lib, core, torch, dist, world, rank, dev, args, all_reduce, prof)
         if pt:
             out.update(pt)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+# ---- ceilings and committed profile summaries --------------------------------------------------------
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak
+VALU_PEAK_NO_FMA_TFLOPS = 78.65  # 157.3 TFLOP/s fp32 vector peak counts a multiply-add as two: plain IEEE multiplies and adds (no contraction,
+#                                  which bit parity with the reference forbids) can reach half of it
+SLAB_FLOPS, TRI_FLOPS = 25, 55   # per ray-box test (RTBase/Geometry.h:216-227) and per Moller-Trumbore test (:99-120)
+NODE_LOADS, GROUP_LOADS = 7, 9   # 16-byte loads per lane: one 4-wide node (112 of its 128 bytes), one leaf fetch (four 36-byte triangle records)
+
+
+def load_profiles():
+    """profiles/r02_ceilings.json: the measured ceiling of per-lane 16-byte gathers (tools/gather_probe.hip);
+    profiles/r02_pmc.json: hardware-counter summaries of the same commands (tools/pmc_collect.sh). Both are
+    committed measurements; a missing file only removes the fields that need it."""
+    out = {}
+    for key, name in (("ceilings", "r02_ceilings.json"), ("pmc", "r02_pmc.json")):
+        try:
+            out[key] = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            out[key] = {}
+    return out
+
+
+def time_closest(core, rays, hits, n, steps, warmup, barrier):
+    """Wall seconds of `steps` launches between two barriers, and the mean kernel duration by HIP events on
+    the launch stream."""
+    for _ in range(warmup):
+        core.trace_closest_device(rays.data_ptr(), n, hits.data_ptr())
+    barrier()
+    t0 = time.perf_counter()
+    core.timer_begin()
+    for _ in range(steps):
+        core.trace_closest_device(rays.data_ptr(), n, hits.data_ptr())
+    kernel_ms = core.timer_end() / max(steps, 1)
+    barrier()
+    return time.perf_counter() - t0, kernel_ms
+
+
+def roofline(n, nodes, tris, groups, kernel_ms, prof, pmc_key):
+    """What bounds the closest-hit kernel and how far it is from it.
+
+    Not HBM: node and triangle fetches are served on chip (the `hbm` block prices the memory-side bytes of the
+    counters against 8 TB/s). Two things saturate together once the tail of a launch is amortised: vector-ALU
+    issue slots and L1 line look-ups (every lane follows its own ray, so a 16-byte load instruction looks up one
+    line per live lane, and an L1 serves about one look-up per clock, measured by tools/gather_probe.hip).
+    `frac` is the work-based VALU figure: flops of the slab and triangle tests the rays need (25 per box,
+    55 per triangle) against the fp32 vector peak for plain multiplies and adds (no fused multiply-add: bit
+    parity with the reference forbids contraction). It factors into the counter readings as
+    frac = valu_busy x live_lane_frac x useful_share x (unpacked / packed issue = 1/2)."""
+    s = kernel_ms * 1e-3
+    pmc = prof["pmc"].get(pmc_key, {}) if pmc_key else {}
+    ceil = prof["ceilings"]
+    flops = 4 * SLAB_FLOPS * nodes + TRI_FLOPS * tris
+    tflops = flops / s / 1e12
+    traffic = pmc.get("hbm_bytes_per_launch")
+    lane_ops = pmc.get("SQ_THREAD_CYCLES_VALU")
+    rays_pmc = pmc.get("rays_per_launch")
+    l1 = pmc.get("l1_lookups_per_clk_per_cu")
+    l1_ceiling = ceil.get("l1_lookups_per_clk_per_cu")
+    r = {"bound": "valu", "achieved": round(tflops, 2), "peak": VALU_PEAK_NO_FMA_TFLOPS, "unit": "TFLOP/s",
+         "frac": round(tflops / VALU_PEAK_NO_FMA_TFLOPS, 4), "traffic": traffic,
+         "kernel": "k_closest", "kernel_ms": round(kernel_ms, 4),
+         "flops_per_ray": round(flops / n, 1), "nodes_per_ray": round(nodes / n, 2), "tris_per_ray": round(tris / n, 2),
+         "leaf_fetches_per_ray": round(groups / n, 2),
+         "valu_busy": pmc.get("valu_busy"), "live_lane_frac": pmc.get("live_lane_frac"),
+         "useful_share_of_lane_ops": round(flops / n / (lane_ops / rays_pmc), 3) if lane_ops and rays_pmc else None,
+         "l1": {"lookups_per_clk_per_cu": l1, "ceiling": l1_ceiling, "frac": round(l1 / l1_ceiling, 3) if l1 and l1_ceiling else None,
+                "ta_busy": pmc.get("ta_busy"), "lane_loads_16B_gbs": round(16.0 * (NODE_LOADS * nodes + GROUP_LOADS * groups) / s / 1e9, 1)},
+         "hbm": {"bytes_per_launch": traffic, "gbs": round(traffic / s / 1e9, 1) if traffic else None, "peak": HBM_PEAK_GBS,
+                 "frac": round(traffic / s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None, "l2_hit": pmc.get("l2_hit"),
+                 "requested_at_cache_level_gbs": round((n * (RAY_BYTES + HIT_BYTES) + nodes * NODE_BYTES + tris * TRI_BYTES) / s / 1e9, 1)},
+         "counters_from": pmc.get("source")}
+    return r
+
+
+def closest_extra(pkg, lib, core, torch, dev, scene, frm, to, fov, width, height, args, prof, pmc_key, barrier):
+    """Closest hit over the pixel-centre primary rays of a width x height film, on `scene` (None: the scene the
+    core holds): Mrays/s by HIP events, work per ray and the same roofline block."""
+    if scene is not None:
+        core.upload_scene(scene)
+    core.set_camera(pkg.look_at(lib, frm, to, (0, 1, 0), fov, width, height))
+    n = width * height
+    rays = torch.empty(n * RAY_BYTES, dtype=torch.uint8, device=dev)
+    hits = torch.empty(n * HIT_BYTES, dtype=torch.uint8, device=dev)
+    core.generate_primary_rays_device(rays.data_ptr(), 0, n)
+    torch.cuda.synchronize()
+    steps = max(3, args.steps // 4)
+    _, kernel_ms = time_closest(core, rays, hits, n, steps, 2, barrier)
+    nodes, tris, groups = core.count_closest_work(rays.data_ptr(), n)
+    st = core.stats()
+    return {"mrays_per_s": round(n / kernel_ms / 1e3, 1), "rays": n, "steps": steps, "bvh4_nodes": st.bvh4_nodes,
+            "roofline": roofline(n, nodes, tris, groups, kernel_ms, prof, pmc_key)}
 
 
 def spawn_ranks(n: int) -> int:
@@ -318,46 +395,79 @@ def cpu_baseline(pkg, scene, cam, args):
     return out
 
 
-def pathtrace_side(pkg, scenes, lib, core, torch, dist, world, rank, dev, args, all_reduce):
-    """1080p path tracing of the mixed-material scene under the environment map
-    (benchmark configuration 2); samples are split over the ranks (shard_mode 2) and the films
-    summed with one RCCL all-reduce at the end."""
+# algorithmic bytes of path state a sample moves through HBM-side memory between the kernels of a pass: per sample
+# ray generation writes its slot (ray 24, film position 8, throughput + radiance 24, rng 8, mis / flags 8, queue 4) and the
+# film kernel reads radiance + position and updates the pixel (12 + 8 + 24); per closest-hit ray the traversal reads the
+# ray and writes the hit (24 + 20 + 4 queue) and the shade kernel reads the slot (ray, hit, throughput, radiance, rng, mis,
+# flags, queue: 112), the triangle's shading record (96) and a texel (12), and writes the continued ray (24 + 12 + 16 + 4
+# queue); per shadow ray the shade kernel writes and the traversal reads segment, value and path (40 each way) and adds to
+# the radiance (24)
+PT_BYTES_PER_SAMPLE, PT_BYTES_PER_CLOSEST, PT_BYTES_PER_SHADOW = 76 + 44, 48 + 220 + 56, 80 + 24
+
+
+def pathtrace_side(pkg, scenes, lib, core, torch, dist, world, rank, dev, args, all_reduce, prof):
+    """1080p path tracing of the mixed-material scene under the environment map (benchmark configuration 2).
+    With several ranks the samples are split (shard_mode 2) and the films summed with one all-reduce at the end,
+    through the same driver a multi-GPU render uses (multigpu.render_sharded)."""
     try:
+        mg = importlib.import_module("ray-tracer_amd.multigpu")
         scene = scenes.mixed_scene(128)
         core.upload_scene(scene)
         cam = pkg.look_at(lib, width=args.width, height=args.height, **scenes.mixed_camera())
         core.set_camera(cam)
-        st = pkg.make_settings(total_spp=args.pt_spp * world, seed=1, shard_mode=2 if world > 1 else 0,
-                               shard_rank=rank, shard_world=world)
-        core.set_settings(st)
+        base = pkg.make_settings(total_spp=args.pt_spp * world, seed=1)
+        core.set_settings(mg.shard_settings(base, rank, world, "spp"))
+        target = mg.CoreTarget(core, torch)
         core.clear()
         core.render_passes(4)          # warm-up (also brings up every pipeline lane's buffers)
         core.clear()
         if world > 1:
-            ptr, nfl = core.film_device()
-            all_reduce(torch.zeros(nfl, dtype=torch.float32, device=dev))     # warm-up of the collective at film size
+            all_reduce(torch.zeros(core.film_device()[1], dtype=torch.float32, device=dev))     # warm-up of the collective at film size
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        core.render_passes(args.pt_spp)
-        if world > 1:
-            ptr, nfl = core.film_device()
-            film = torch.empty(nfl, dtype=torch.float32, device=dev)
-            ctypes.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(ctypes.c_void_p(film.data_ptr()), ctypes.c_void_p(ptr),
-                                                                   ctypes.c_size_t(nfl * 4), 3)
-            all_reduce(film)
+        mg.render_sharded(target, base, dist, rank, world, "spp")
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             all_reduce(t, dist.ReduceOp.MAX)
             dt = float(t.item())
-        s = core.stats()
-        return {"pathtrace_spp_per_s": round(args.pt_spp * world / dt, 3),
-                "pathtrace_config": {"workload": f"configs[2]: mixed Diffuse/Mirror/Glass/Conductor/Plastic scene ({scene.n_triangles} triangles) + 1024x512 env-map MIS, {args.width}x{args.height}, maxBounces 5",
-                                     "spp_timed": args.pt_spp * world, "parallelism": f"spp split x{world} + film all-reduce" if world > 1 else "1 GPU"}}
+        out = {"pathtrace_spp_per_s": round(args.pt_spp * world / dt, 3),
+               "pathtrace_config": {"workload": f"configs[2]: mixed Diffuse/Mirror/Glass/Conductor/Plastic scene ({scene.n_triangles} triangles) + 1024x512 env-map MIS, {args.width}x{args.height}, maxBounces 5",
+                                    "spp_timed": args.pt_spp * world, "parallelism": f"spp split x{world} + film all-reduce" if world > 1 else "1 GPU"}}
+        if rank == 0 and world == 1:
+            out["pathtrace_roofline"] = pathtrace_roofline(core, dt / args.pt_spp, prof)
+        return out
     except pkg.RtxError as e:
         return {"pathtrace_spp_per_s": None, "pathtrace_error": str(e)}
+
+
+def pathtrace_roofline(core, s_per_pass, prof):
+    """A pass is a chain of kernels bound by two different things: the traversal launches like the headline kernel
+    (vector-ALU issue and L1 look-ups), ray generation / shading / film by HBM-side traffic of path state. The floor of
+    a pass is the sum of both resource times for the work two instrumented passes count (traversal flops at the
+    un-fused fp32 vector peak + algorithmic state bytes at 8 TB/s); frac = floor / measured."""
+    core.clear()
+    w = core.count_render_work(2)
+    k = w["samples"]
+    per = {key: w[key] / k for key in ("closest_rays", "shadow_rays", "nodes", "tris", "tri_groups")}
+    flops = (4 * SLAB_FLOPS * w["nodes"] + TRI_FLOPS * w["tris"]) / 2
+    state_bytes = (PT_BYTES_PER_SAMPLE * w["samples"] + PT_BYTES_PER_CLOSEST * w["closest_rays"] + PT_BYTES_PER_SHADOW * w["shadow_rays"]) / 2
+    pmc = prof["pmc"].get("pathtrace", {})
+    r = {"bound": "valu (traversal kernels) + hbm (ray generation, shading, film)", "ms_per_pass": round(s_per_pass * 1e3, 4),
+         "rays_per_sample": {"closest": round(per["closest_rays"], 3), "shadow": round(per["shadow_rays"], 3)},
+         "nodes_per_sample": round(per["nodes"], 2), "tris_per_sample": round(per["tris"], 2),
+         "traversal_flops_per_pass": int(flops), "state_bytes_per_pass": int(state_bytes),
+         "useful_tflops": round(flops / s_per_pass / 1e12, 2), "state_gbs": round(state_bytes / s_per_pass / 1e9, 1)}
+    floor = flops / (VALU_PEAK_NO_FMA_TFLOPS * 1e12) + state_bytes / (HBM_PEAK_GBS * 1e9)
+    r.update({"floor_ms_per_pass": round(floor * 1e3, 4), "frac": round(floor / s_per_pass, 4),
+              "valu_peak_no_fma_tflops": VALU_PEAK_NO_FMA_TFLOPS, "hbm_peak_gbs": HBM_PEAK_GBS})
+    if pmc:
+        r["kernels"] = pmc.get("kernels")
+        r["hbm_bytes_per_pass"] = pmc.get("hbm_bytes_per_pass")
+        r["counters_from"] = pmc.get("source")
+    return r
 
 
 if __name__ == "__main__":

@@ -274,9 +274,17 @@ int rtx_timer_end(rtx_ctx* ctx, float* ms);
 
 /* Algorithmic traffic of the closest-hit kernel for the rays of the last
  * rtx_trace_closest* call, counted by an instrumented device pass over the same layout:
- * wide nodes visited (128 B each) and triangles tested (36 B each), summed over rays. */
+ * wide nodes visited (128 B each, seven 16-byte loads per lane), triangles tested (36 B each) and leaf fetches
+ * (up to four triangles = nine 16-byte loads per lane; tri_groups may be NULL), summed over rays. */
 int rtx_count_closest_work(rtx_ctx* ctx, const rtx_ray* rays_dev, size_t n,
-                           uint64_t* nodes_visited, uint64_t* tris_tested);
+                           uint64_t* nodes_visited, uint64_t* tris_tested, uint64_t* tri_groups);
+
+/* The same for the renderer: n_passes passes exactly like rtx_render_passes renders them (the film advances, results
+ * are identical), one at a time, with the traversal kernels instrumented. out[0] = closest-hit rays (live paths
+ * summed over depths), out[1] = shadow / camera-connection segments, out[2] = wide nodes visited and out[3] = triangles
+ * tested by all of them, out[4] = pixel samples (light paths) started, out[5] = leaf fetches. The visibility walks
+ * inside the instant-radiosity gather (pixels x VPLs) are not counted. */
+int rtx_count_render_work(rtx_ctx* ctx, int n_passes, uint64_t out[6]);
 
 #ifdef __cplusplus
 }

@@ -172,7 +172,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "rtx_create_aov": [vp, vp, vp, vp], "rtx_create_aov_device": [vp, vp, vp, vp],
         "rtx_get_stats": [vp, C.POINTER(Stats)], "rtx_reset_stats": [vp],
         "rtx_timer_begin": [vp], "rtx_timer_end": [vp, C.POINTER(C.c_float)],
-        "rtx_count_closest_work": [vp, vp, sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+        "rtx_count_closest_work": [vp, vp, sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+        "rtx_count_render_work": [vp, C.c_int, C.POINTER(C.c_uint64)],
     }
     sig["rtx_host_bvh_build"] = [C.POINTER(SceneDesc), C.POINTER(vp)]
     sig["rtx_host_bvh_get"] = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), vp, vp, vp, C.POINTER(C.c_uint32),
@@ -328,9 +329,15 @@ class Core:
         self._check(self.lib.rtx_generate_primary_rays_device(self.ctx, rays_ptr, pixel_ptr, capacity))
 
     def count_closest_work(self, rays_ptr: int, n: int):
-        a, b = C.c_uint64(), C.c_uint64()
-        self._check(self.lib.rtx_count_closest_work(self.ctx, rays_ptr, n, C.byref(a), C.byref(b)))
-        return a.value, b.value
+        a, b, g = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self.lib.rtx_count_closest_work(self.ctx, rays_ptr, n, C.byref(a), C.byref(b), C.byref(g)))
+        return a.value, b.value, g.value
+
+    def count_render_work(self, n_passes: int = 1) -> dict:
+        """n instrumented passes (the film advances as usual): rays, nodes visited, triangles tested."""
+        out = (C.c_uint64 * 6)()
+        self._check(self.lib.rtx_count_render_work(self.ctx, n_passes, out))
+        return dict(zip(("closest_rays", "shadow_rays", "nodes", "tris", "samples", "tri_groups"), (int(v) for v in out)))
 
     # introspection
     def bvh(self):

@@ -49,6 +49,7 @@ struct rtx_ctx {
     int device = 0;
     int variant = 1;               // traversal schedule (RTX_VARIANT): 1 = default, 0 = static baseline, >= 2 = schedules under test
     int resident_blocks = rtx::kMaxGridBlocks;   // traversal workgroups the device holds at once
+    int rays_per_block = 16;       // grid of a ray-query launch too small to fill the device: one workgroup per this many rays
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -74,6 +75,7 @@ struct rtx_ctx {
     uint32_t tiles_x = 0, tiles_y = 0;
     rtx::WavefrontBuffers* wf[rtx::kPipeline] = {};   // path state of the passes in flight; [0] always exists once a camera is set
     int pipeline = 3;                                  // passes rtx_render_passes keeps in flight (RTX_PIPELINE); 3 + the caller's stream fit the 4 hardware queues
+    int passes_in_flight = 1;                          // set by rtx_render_passes for the passes it is enqueueing
     int spill_lanes = 1;                               // traversal-stack slabs in b_spill
     hipStream_t pipe_stream[rtx::kPipeline] = {};
     hipStream_t aux_stream[rtx::kPipeline] = {};       // per lane: shadow rays of depth d run beside the closest hits of depth d + 1
@@ -82,5 +84,6 @@ struct rtx_ctx {
     int overlap = 1;                                   // used when a call renders one pass at a time; RTX_OVERLAP=0 keeps a pass on one stream
     hipEvent_t pipe_film[rtx::kPipeline] = {}, pipe_done[rtx::kPipeline] = {}, ev_fork = nullptr, ev_tiles = nullptr;
 
+    bool count_work = false;       // render passes run the instrumented traversal kernels (rtx_count_render_work)
     rtx_stats stats{};
 };

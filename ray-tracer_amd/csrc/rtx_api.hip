@@ -40,8 +40,9 @@ int upload(DevBuf& b, const std::vector<T>& v, hipStream_t s)
 }
 
 int grid_for(size_t n) { return (int)std::min<size_t>((n + kBlock - 1) / kBlock, kMaxGridBlocks); }
-// kernels that fetch their work dynamically only need the workgroups that are resident at once
-int dyn_grid_for(const rtx_ctx* c, size_t n) { return (int)std::min<size_t>((n + kBlock - 1) / kBlock, (size_t)c->resident_blocks); }
+// kernels that fetch their work dynamically only need the workgroups that are resident at once; a launch too small to
+// fill them gets up to 16 lanes per ray, which the traversal spends on walking a ray's pending subtrees side by side
+int dyn_grid_for(const rtx_ctx* c, size_t n) { const size_t per = (size_t)c->rays_per_block; return (int)std::min<size_t>((n + per - 1) / per, (size_t)c->resident_blocks); }
 
 // ---- scratch of the entry point that allocates nothing (rtx_trace_closest_device_noalloc) -------------------
 // The closest-hit kernel needs two pieces of device memory beyond rays and hits: the work counters its waves draw
@@ -141,6 +142,7 @@ static int create_resources(rtx_ctx* c, int device)
     }
     if (const char* v = getenv("RTX_OVERLAP")) c->overlap = atoi(v) != 0;
     if (const char* v = getenv("RTX_MERGE")) c->merge_shadow = atoi(v) != 0;
+    if (const char* v = getenv("RTX_RAYS_PER_BLOCK")) c->rays_per_block = std::max(1, std::min(kBlock, atoi(v)));
     if (const char* v = getenv("RTX_PIPELINE")) c->pipeline = std::max(1, std::min(kPipeline, atoi(v)));
     HIP_TRY(c->b_counters.ensure(4 * (1 + 2) * kWorkSlotWords));   // instrumentation counters, then the work-counter slots of the closest-hit and visibility launches
     // RayTracer's defaults, RTBase/Settings.h:40-61
@@ -227,6 +229,8 @@ int rtx_upload_scene(rtx_ctx* c, const rtx_scene_desc* d)
     ds.env_guide_rows = c->b_env_guide_rows.as<uint32_t>(); ds.env_guide_cols = c->b_env_guide_cols.as<uint32_t>();
     ds.env_inv_w = h.env_w ? 1.0f / (float)h.env_w : 0.f; ds.env_inv_h = h.env_h ? 1.0f / (float)h.env_h : 0.f;
     ds.scene_radius = h.scene_radius;
+    ds.spread_below = 32;
+    if (const char* v = getenv("RTX_SPREAD")) ds.spread_below = (uint32_t)std::max(0, std::min(32, atoi(v)));   // tuning override
 
     // traversal stack: at most three pushes per wide level, or one pending node per binary
     // level on the exact path; entries beyond the LDS part go to global memory
@@ -321,6 +325,7 @@ int rtx_render_passes(rtx_ctx* c, int n)
     // own: late bounces hold few rays and a launch then lasts as long as its slowest ray, so
     // the passes fill each other's idle lanes. The film is still summed in pass order.
     const int lanes = std::max(1, std::min(n, c->pipeline));
+    c->passes_in_flight = lanes;
     if (c->spill_lanes < 2) { c->spill_lanes = 2; int rc = ensure_spill(c); if (rc) return rc; }
     if (lanes == 1) {
         for (int i = 0; i < n; i++) {
@@ -591,7 +596,7 @@ int rtx_generate_primary_rays_device(rtx_ctx* c, rtx_ray* rays, uint32_t* pixel,
     return RTX_OK;
 }
 
-int rtx_count_closest_work(rtx_ctx* c, const rtx_ray* rays, size_t n, uint64_t* nodes, uint64_t* tris)
+int rtx_count_closest_work(rtx_ctx* c, const rtx_ray* rays, size_t n, uint64_t* nodes, uint64_t* tris, uint64_t* tri_groups)
 {
     CTX_TRY(c);
     if (!c->have_scene) return fail(RTX_ERR_STATE, "no scene uploaded");
@@ -602,8 +607,8 @@ int rtx_count_closest_work(rtx_ctx* c, const rtx_ray* rays, size_t n, uint64_t* 
                        (uint32_t)n, (const uint32_t*)nullptr, c->b_io_b.as<rtx_hit>(), c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock),
                        c->b_counters.as<uint32_t>() + kWorkSlotWords, c->b_counters.as<unsigned long long>());
     HIP_TRY(hipGetLastError());
-    unsigned long long h[5];
-    HIP_TRY(hipMemcpyAsync(h, c->b_counters.p, 40, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long h[6];
+    HIP_TRY(hipMemcpyAsync(h, c->b_counters.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (getenv("RTX_DEBUG_COUNTERS")) {
         // distribution of the dependent steps of a ray (node visits + groups of four triangle tests): the slowest
@@ -620,6 +625,35 @@ int rtx_count_closest_work(rtx_ctx* c, const rtx_ray* rays, size_t n, uint64_t* 
     if (getenv("RTX_DEBUG_COUNTERS"))
         fprintf(stderr, "[rtx] lane node visits %llu, lane tri tests %llu; wave inner trips %llu, wave tri trips %llu, wave outer trips %llu\n", h[0], h[1], h[2], h[3], h[4]);
     *nodes = h[0]; *tris = h[1];
+    if (tri_groups) *tri_groups = h[5];
+    return RTX_OK;
+}
+
+int rtx_count_render_work(rtx_ctx* c, int n_passes, uint64_t out[6])
+{
+    CTX_TRY(c);
+    if (!c->have_scene || !c->have_camera) return fail(RTX_ERR_STATE, "scene and camera must be set before rendering");
+    if (!out || n_passes < 1) return fail(RTX_ERR_INVALID, "bad argument");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemsetAsync(c->b_counters.p, 0, 4 * kWorkSlotWords, c->stream));
+    if (c->spill_lanes < 2) { c->spill_lanes = 2; int rc = ensure_spill(c); if (rc) return rc; }
+    for (int i = 0; i < 6; i++) out[i] = 0;
+    std::vector<uint32_t> q(2 * 96);
+    c->count_work = true; c->passes_in_flight = 1;
+    for (int i = 0; i < n_passes; i++) {
+        const uint64_t before = c->stats.samples;
+        int rc = wavefront_render_pass(c, 0, c->stream, nullptr, nullptr, false);
+        hipError_t e = rc ? hipSuccess : hipMemcpyAsync(q.data(), c->wf[0]->p.cnt, q.size() * 4, hipMemcpyDeviceToHost, c->stream);
+        if (!rc && e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (rc || e != hipSuccess) { c->count_work = false; return fail(rc ? rc : RTX_ERR_HIP, "instrumented render pass failed: %s", hipGetErrorString(e)); }
+        // queue lengths of the pass: live paths per depth (one closest-hit ray each), shadow / connection segments per depth
+        for (int d = 0; d < 96; d++) { out[0] += q[d]; out[1] += q[96 + d]; }
+        out[4] += c->stats.samples - before;
+    }
+    c->count_work = false;
+    unsigned long long h[6];
+    HIP_TRY(hipMemcpy(h, c->b_counters.p, sizeof h, hipMemcpyDeviceToHost));
+    out[2] = h[0]; out[3] = h[1]; out[5] = h[5];
     return RTX_OK;
 }
 

@@ -37,7 +37,7 @@ constexpr float kCullAbs = 1e-6f;
 struct HitRec { float t, u, v; uint32_t pos; };   // pos = leaf-order position, 0xFFFFFFFF = none
 
 // Work counters of an instrumented traversal (algorithmic traffic of the layout)
-struct TravCount { uint32_t nodes, tris; };
+struct TravCount { uint32_t nodes, tris, groups; };   // groups: leaf-triangle fetches (up to four triangles each)
 
 // Triangle::rayIntersect, RTBase/Geometry.h:95-126, same operation order.
 __device__ __forceinline__ bool tri_test(const TriIsect& T, float ox, float oy, float oz, float dx, float dy, float dz,

@@ -89,7 +89,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
     constexpr uint32_t kHelper = 0xFFFFFF00u;
     const uint32_t wave0 = threadIdx.x & ~63u;
     bool tail = false;   // SHARE: the mailboxes are set up
-    TravCount cnt{0, 0}, mark{0, 0};   // mark: the counters when the lane's current ray started (COUNT only)
+    TravCount cnt{0, 0, 0}, mark{0, 0, 0};   // mark: the counters when the lane's current ray started (COUNT only)
     uint32_t wave_iters[3] = {0, 0, 0};   // COUNT only: inner-loop, triangle-loop and outer-loop trips of this lane
     uint32_t cur = kDone, item = kNone;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, bound = FLT_MAX, maxT = 0;
@@ -103,7 +103,24 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
     // over kWorkSegments addresses instead of queueing on one. A wave draws from the counter
     // of its workgroup; when that one has run dry it looks at all counters at once (one
     // coherent load per lane) and moves to one that still has chunks. Wave-uniform state.
-    const uint32_t n_chunks = (n + 63u) / 64u;
+    //
+    // Small launches (fewer than half a wave of items per wave of the grid) are spread instead: chunks of 1 .. 32 items,
+    // so that every wave of the grid gets some, a wave fetches again only when all its lanes are free, and the
+    // lanes it does not need for rays of their own help from the first step on (see TailShare). Such a launch is
+    // not limited by throughput but by the dependent node fetches of its longest rays, and the helpers walk
+    // the pending subtrees of a ray side by side.
+    uint32_t chunk = 64u, refill = (uint32_t)REFILL;
+    bool spread = false, eager = false;   // eager: most lanes are free, so pending children are handed to them after every level
+    if constexpr (SHARE != 0) {
+        const uint32_t waves = gridDim.x * (uint32_t)(BLOCK / 64);
+        if ((unsigned long long)n < (unsigned long long)waves * sc.spread_below) {
+            const uint32_t per = (n + waves - 1u) / waves;
+            chunk = 1u; while (chunk < per) chunk <<= 1;
+            refill = 64u; spread = true; eager = chunk <= 8u;
+            ts->key[threadIdx.x] = pack_hit(best); ts->pending[threadIdx.x] = 0u; tail = true;
+        }
+    }
+    const uint32_t n_chunks = (n + chunk - 1u) / chunk;
     uint32_t seg = blockIdx.x % (uint32_t)kWorkSegments, loc_next = 0, loc_end = 0;
     bool exhausted = false;
     for (;;) {
@@ -141,7 +158,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
         }
         unsigned long long m = __ballot(cur == kDone && item == kNone);
         uint32_t n_idle = (uint32_t)__popcll(m);
-        while (!exhausted && n_idle >= (uint32_t)REFILL) {
+        while (!exhausted && n_idle >= refill) {
             if (loc_next == loc_end) {
                 uint32_t j = 0;
                 if (lane == 0) j = atomicAdd(work + seg * (uint32_t)kWorkStride, 1u);
@@ -158,7 +175,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
                     seg = (seg + (uint32_t)__ffsll((long long)rot) - 1u) & 63u;
                     continue;
                 }
-                loc_next = g * 64u; loc_end = min(loc_next + 64u, n);
+                loc_next = g * chunk; loc_end = min(loc_next + chunk, n);
             }
             const uint32_t take = min(n_idle, loc_end - loc_next);
             const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -169,6 +186,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
                 ox = o[0]; oy = o[1]; oz = o[2]; dx = d[0]; dy = d[1]; dz = d[2];
                 ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;                                    // Ray::init, Geometry.h:25
                 best.t = FLT_MAX; best.u = best.v = 0; best.pos = kNone; stk.sp = 0;
+                if constexpr (SHARE != 0) { if (tail) { ts->key[threadIdx.x] = pack_hit(best); ts->pending[threadIdx.x] = 0u; } }   // a fresh mailbox for the new ray
                 bound = RTX_IS_ANY ? (maxT + (fabsf(maxT) * kCullRel + kCullAbs)) : FLT_MAX;
                 // root box first (Geometry.h:509 / :571)
                 if (slab_reference(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ox, oy, oz, ix, iy, iz)) {
@@ -188,7 +206,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
             n_idle = (uint32_t)__popcll(m);
         }
         if constexpr (SHARE) {
-            if (exhausted) {
+            if (exhausted || spread) {
                 if (!tail) { ts->key[threadIdx.x] = pack_hit(best); ts->pending[threadIdx.x] = 0u; tail = true; }
                 const unsigned long long freeM = __ballot(cur == kDone && item == kNone);
                 const unsigned long long donM = __ballot(cur != kDone && stk.sp > 0);
@@ -238,6 +256,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
                 if (!__any(inner)) break;
                 if (inner) { if (COUNT) wave_iters[0]++; cur = step_inner<COUNT, BLOCK, LDS_N, MODE == kModeAny ? 1 : 0>(sc, stk, cur, ox, oy, oz, ix, iy, iz, bound, &cnt); }
                 if (__popcll(__ballot((cur & kLeafBit) != 0)) >= SCHED) break;
+                if (eager) break;      // one level at a time: the children just pushed go to free lanes at once
             }
         }
         if (cur & kLeafBit) {
@@ -257,7 +276,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
 #pragma unroll
                     for (int j = 0; j < TRI_UNROLL; j++) T[j] = sc.tris[first + min(k + (uint32_t)j, nt - 1u)];
                 }
-                if (COUNT) wave_iters[1]++;
+                if (COUNT) { wave_iters[1]++; cnt.groups++; }
 #pragma unroll
                 for (int j = 0; j < TRI_UNROLL; j++) {
                     if (k + (uint32_t)j < nt) {
@@ -294,7 +313,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
     }
 #undef RTX_IS_ANY
     if (COUNT) {
-        atomicAdd(&counters[0], (unsigned long long)cnt.nodes); atomicAdd(&counters[1], (unsigned long long)cnt.tris);
+        atomicAdd(&counters[0], (unsigned long long)cnt.nodes); atomicAdd(&counters[1], (unsigned long long)cnt.tris); atomicAdd(&counters[5], (unsigned long long)cnt.groups);
         // wave-level trip counts: the maximum over the lanes of a wave is what the wave executed
         for (int q = 0; q < 3; q++) {
             uint32_t v = wave_iters[q];

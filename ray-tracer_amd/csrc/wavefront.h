@@ -320,14 +320,33 @@ struct ShadowAccumulatePolicy {
             st3(w.L + 3 * slot, L);
         }
     }
+    __device__ __forceinline__ void note(uint32_t, uint32_t, uint32_t) const {}
 };
-__global__ __launch_bounds__(kBlock) void k_shadow_accumulate(WfPtrs w, DeviceScene sc, uint32_t counter_index, uint32_t work_index, uint2* spill, uint32_t spill_stride)
+// COUNT (here and in the kernels below): the instrumented variant behind rtx_count_render_work — same results, plus
+// the nodes visited / triangles tested by one lane per ray (no helpers) added to counters[0..1]
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_shadow_accumulate(WfPtrs w, DeviceScene sc, uint32_t counter_index, uint32_t work_index, uint2* spill, uint32_t spill_stride,
+                                                              unsigned long long* counters)
 {
     __shared__ unsigned long long lds[kBlock * kLdsStack];
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     ShadowAccumulatePolicy pol{w};
     __shared__ TailShare<kBlock> ts;
-    traverse_dyn<ShadowAccumulatePolicy, kModeAny, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, nullptr, &ts);
+    traverse_dyn<ShadowAccumulatePolicy, kModeAny, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, COUNT ? 0 : kShare>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, counters, &ts);
+}
+// closest hits of a queue with the work counters on (the plain policy's note() keeps per-ray counts in the hit record,
+// which a render pass needs intact)
+struct ClosestQuietPolicy : ClosestPolicy {
+    __device__ __forceinline__ void note(uint32_t, uint32_t, uint32_t) const {}
+};
+__global__ __launch_bounds__(kBlock) void k_closest_counted(DeviceScene sc, const rtx_ray* __restrict__ rays, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ n_dev,
+                                                            rtx_hit* __restrict__ hits, uint2* spill, uint32_t spill_stride, uint32_t* work_counter, unsigned long long* counters)
+{
+    __shared__ unsigned long long lds[kBlock * kLdsStack];
+    LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
+    ClosestQuietPolicy pol{{sc, rays, queue, hits}};
+    __shared__ TailShare<kBlock> ts;
+    traverse_dyn<ClosestQuietPolicy, kModeClosest, true, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, 0>(sc, stk, *n_dev, work_counter, pol, counters, &ts);
 }
 
 // The shadow rays of depth d - 1 and the closest-hit rays of depth d in ONE launch: neither depends on the other
@@ -352,17 +371,19 @@ struct PtMixedPolicy {
             st3(w.L + 3 * slot, L);
         }
     }
+    __device__ __forceinline__ void note(uint32_t, uint32_t, uint32_t) const {}
 };
 // (the per-item flag costs registers: held to the 96 that keep five waves per SIMD like the other traversal kernels; +3 % on a 1080p pass)
+template <bool COUNT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_pt_trace_mixed(WfPtrs w, DeviceScene sc, uint32_t depth, const uint32_t* __restrict__ queue, uint32_t work_index,
-                                                           uint2* spill, uint32_t spill_stride)
+                                                           uint2* spill, uint32_t spill_stride, unsigned long long* counters)
 {
     __shared__ unsigned long long lds[kBlock * kLdsStack];
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     const uint32_t n_closest = w.cnt[depth], n_shadow = w.cnt[kShadowCounterBase + depth - 1];
     PtMixedPolicy pol{sc, w, queue, n_closest};
     __shared__ TailShare<kBlock> ts;
-    traverse_dyn<PtMixedPolicy, kModeMixed, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, n_closest + n_shadow, w.cnt + work_index, pol, nullptr, &ts);
+    traverse_dyn<PtMixedPolicy, kModeMixed, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, COUNT ? 0 : kShare>(sc, stk, n_closest + n_shadow, w.cnt + work_index, pol, counters, &ts);
 }
 
 // film->splat(px, py, col) for every sample of the pass, Renderer.h:745
@@ -811,14 +832,27 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
     uint2* spill = c->b_spill.as<uint2>() + (size_t)(2 * lane) * c->spill_entries * sstride;
     uint2* spill_aux = spill + (size_t)c->spill_entries * sstride;      // traversal stacks of the kernels on the lane's second stream
 
+    // several passes in flight fill each other's idle lanes: spreading a small launch thin (helpers walking speculative
+    // subtrees) then only takes throughput away from the other passes, so it is kept for launches that are nearly empty
+    DeviceScene dscene = c->dscene;
+    if (c->passes_in_flight > 1) dscene.spread_below = std::min<uint32_t>(dscene.spread_below, 2u);
+
     c->spp++;                                            // Film::incrementSPP, RTBase/Imaging.h:403
     PassParams pp; pp.st = st; pp.spp = c->spp; pp.depth = 0;
     pp.sample_index = (st.shard_mode == 2 && st.shard_world > 1) ? (uint32_t)(c->spp - 1) * (uint32_t)st.shard_world + (uint32_t)st.shard_rank + 1u : (uint32_t)c->spp;
     if (hipMemsetAsync(w.cnt, 0, kCounterWords * 4, s) != hipSuccess) return RTX_ERR_HIP;
 
+    const bool cw = c->count_work;                       // instrumented kernels (rtx_count_render_work)
+    unsigned long long* ctr = cw ? c->b_counters.as<unsigned long long>() : nullptr;
     auto closest = [&](const uint32_t* queue, uint32_t counter) {
-        hipLaunchKernelGGL(k_closest<false>, gridT, blk, 0, s, c->dscene, (const rtx_ray*)w.ray, queue, 0u, (const uint32_t*)(w.cnt + counter), w.hit, spill, sstride,
+        if (cw) hipLaunchKernelGGL(k_closest_counted, gridT, blk, 0, s, dscene, (const rtx_ray*)w.ray, queue, (const uint32_t*)(w.cnt + counter), w.hit, spill, sstride,
+                                   w.cnt + kClosestWorkBase + counter * kWorkSlotWords, ctr);
+        else hipLaunchKernelGGL(k_closest<false>, gridT, blk, 0, s, dscene, (const rtx_ray*)w.ray, queue, 0u, (const uint32_t*)(w.cnt + counter), w.hit, spill, sstride,
                            w.cnt + kClosestWorkBase + counter * kWorkSlotWords, (unsigned long long*)nullptr);
+    };
+    auto shadow = [&](hipStream_t on, uint32_t counter_index, uint32_t work_index, uint2* stacks) {
+        if (cw) hipLaunchKernelGGL(k_shadow_accumulate<true>, gridT, blk, 0, on, w, dscene, counter_index, work_index, stacks, sstride, ctr);
+        else hipLaunchKernelGGL(k_shadow_accumulate<false>, gridT, blk, 0, on, w, dscene, counter_index, work_index, stacks, sstride, (unsigned long long*)nullptr);
     };
     const bool algo = st.draw_mode == RTX_DM_ALGORITHM;
 
@@ -827,8 +861,8 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, w, pp);
         hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
         closest(w.qa, 0);
-        hipLaunchKernelGGL(k_dm_shade, gridQ, blk, 0, s, w, c->dscene, pp);
-        hipLaunchKernelGGL(k_shadow_accumulate, gridT, blk, 0, s, w, c->dscene, (uint32_t)kShadowCounterBase, (uint32_t)kShadowWorkBase, spill, sstride);
+        hipLaunchKernelGGL(k_dm_shade, gridQ, blk, 0, s, w, dscene, pp);
+        shadow(s, (uint32_t)kShadowCounterBase, (uint32_t)kShadowWorkBase, spill);
         if (film_wait && hipStreamWaitEvent(s, film_wait, 0) != hipSuccess) return RTX_ERR_HIP;
         launch_film_accumulate(w, (int)st.filter, gridP, blk, s);
         c->stats.samples += (uint64_t)w.W * w.H;
@@ -842,12 +876,13 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
             for (uint32_t d = 0; d <= st.max_bounces; d++) {
                 pp.depth = d;
                 if (d == 0) closest(qin, 0);
-                else hipLaunchKernelGGL(k_pt_trace_mixed, gridT, blk, 0, s, w, c->dscene, d, (const uint32_t*)qin, (uint32_t)(kClosestWorkBase + d * kWorkSlotWords), spill, sstride);
-                hipLaunchKernelGGL(k_pt_shade, gridQ, blk, 0, s, w, c->dscene, pp, (const uint32_t*)qin, qout);
+                else if (cw) hipLaunchKernelGGL(k_pt_trace_mixed<true>, gridT, blk, 0, s, w, dscene, d, (const uint32_t*)qin, (uint32_t)(kClosestWorkBase + d * kWorkSlotWords), spill, sstride, ctr);
+                else hipLaunchKernelGGL(k_pt_trace_mixed<false>, gridT, blk, 0, s, w, dscene, d, (const uint32_t*)qin, (uint32_t)(kClosestWorkBase + d * kWorkSlotWords), spill, sstride,
+                                        (unsigned long long*)nullptr);
+                hipLaunchKernelGGL(k_pt_shade, gridQ, blk, 0, s, w, dscene, pp, (const uint32_t*)qin, qout);
                 std::swap(qin, qout);
             }
-            hipLaunchKernelGGL(k_shadow_accumulate, gridT, blk, 0, s, w, c->dscene, (uint32_t)(kShadowCounterBase + st.max_bounces),
-                               (uint32_t)(kShadowWorkBase + st.max_bounces * kWorkSlotWords), spill, sstride);
+            shadow(s, (uint32_t)(kShadowCounterBase + st.max_bounces), (uint32_t)(kShadowWorkBase + st.max_bounces * kWorkSlotWords), spill);
         } else {
         // The shadow rays of depth d and the closest hits of depth d + 1 do not depend on each other:
         // the former run on the lane's second stream. The shade kernel of depth d + 1 waits for them
@@ -858,10 +893,9 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
             pp.depth = d;
             closest(qin, d);
             if (overlap && d > 0 && hipStreamWaitEvent(s, c->ev_shadow[lane], 0) != hipSuccess) return RTX_ERR_HIP;
-            hipLaunchKernelGGL(k_pt_shade, gridQ, blk, 0, s, w, c->dscene, pp, (const uint32_t*)qin, qout);
+            hipLaunchKernelGGL(k_pt_shade, gridQ, blk, 0, s, w, dscene, pp, (const uint32_t*)qin, qout);
             if (overlap && (hipEventRecord(c->ev_shade[lane], s) != hipSuccess || hipStreamWaitEvent(sa, c->ev_shade[lane], 0) != hipSuccess)) return RTX_ERR_HIP;
-            hipLaunchKernelGGL(k_shadow_accumulate, gridT, blk, 0, sa, w, c->dscene, (uint32_t)(kShadowCounterBase + d), (uint32_t)(kShadowWorkBase + d * kWorkSlotWords),
-                               overlap ? spill_aux : spill, sstride);
+            shadow(sa, (uint32_t)(kShadowCounterBase + d), (uint32_t)(kShadowWorkBase + d * kWorkSlotWords), overlap ? spill_aux : spill);
             if (overlap && hipEventRecord(c->ev_shadow[lane], sa) != hipSuccess) return RTX_ERR_HIP;
             std::swap(qin, qout);
         }
@@ -871,14 +905,14 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         launch_film_accumulate(w, (int)st.filter, gridP, blk, s);
         c->stats.samples += (uint64_t)w.W * w.H;
     } else if (st.algorithm == RTX_AL_LIGHT_TRACE) {
-        hipLaunchKernelGGL(k_lt_emit, gridP, blk, 0, s, w, c->dscene, c->dcam, pp);
-        hipLaunchKernelGGL(k_lt_splat, gridT, blk, 0, s, w, c->dscene, (uint32_t)(kShadowCounterBase + 95), (uint32_t)(kShadowWorkBase + 95 * kWorkSlotWords), (int)st.filter, spill, sstride);
+        hipLaunchKernelGGL(k_lt_emit, gridP, blk, 0, s, w, dscene, c->dcam, pp);
+        hipLaunchKernelGGL(k_lt_splat, gridT, blk, 0, s, w, dscene, (uint32_t)(kShadowCounterBase + 95), (uint32_t)(kShadowWorkBase + 95 * kWorkSlotWords), (int)st.filter, spill, sstride);
         uint32_t* qin = w.qa; uint32_t* qout = w.qb;
         for (uint32_t d = 0; d < st.max_bounces; d++) {
             pp.depth = d;
             closest(qin, d);
-            hipLaunchKernelGGL(k_lt_shade, gridQ, blk, 0, s, w, c->dscene, c->dcam, pp, (const uint32_t*)qin, qout);
-            hipLaunchKernelGGL(k_lt_splat, gridT, blk, 0, s, w, c->dscene, (uint32_t)(kShadowCounterBase + d), (uint32_t)(kShadowWorkBase + d * kWorkSlotWords), (int)st.filter, spill, sstride);
+            hipLaunchKernelGGL(k_lt_shade, gridQ, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
+            hipLaunchKernelGGL(k_lt_splat, gridT, blk, 0, s, w, dscene, (uint32_t)(kShadowCounterBase + d), (uint32_t)(kShadowWorkBase + d * kWorkSlotWords), (int)st.filter, spill, sstride);
             std::swap(qin, qout);
         }
         c->stats.samples += (uint64_t)w.W * w.H;
@@ -891,12 +925,12 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         w.vpl = b.vpl.as<float>(); w.vpl_slots = slots;
         if (slots && hipMemsetAsync(w.vpl, 0, (size_t)slots * 40, s) != hipSuccess) return RTX_ERR_HIP;
         if (n_paths) {
-            hipLaunchKernelGGL(k_vpl_emit, dim3((n_paths + kBlock - 1) / kBlock), blk, 0, s, w, c->dscene, pp, n_paths);
+            hipLaunchKernelGGL(k_vpl_emit, dim3((n_paths + kBlock - 1) / kBlock), blk, 0, s, w, dscene, pp, n_paths);
             uint32_t* qin = w.qa; uint32_t* qout = w.qb;
             for (uint32_t d = 0; d < st.max_bounces; d++) {
                 pp.depth = d;
                 closest(qin, d);
-                hipLaunchKernelGGL(k_vpl_shade, gridQ, blk, 0, s, w, c->dscene, pp, (const uint32_t*)qin, qout);
+                hipLaunchKernelGGL(k_vpl_shade, gridQ, blk, 0, s, w, dscene, pp, (const uint32_t*)qin, qout);
                 std::swap(qin, qout);
             }
         }
@@ -907,7 +941,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, w, pp);
         hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
         closest(w.qa, 0);
-        hipLaunchKernelGGL(k_ir_gather, gridQ, blk, 0, s, w, c->dscene, pp, spill, sstride);
+        hipLaunchKernelGGL(k_ir_gather, gridQ, blk, 0, s, w, dscene, pp, spill, sstride);
         if (film_wait && hipStreamWaitEvent(s, film_wait, 0) != hipSuccess) return RTX_ERR_HIP;
         launch_film_accumulate(w, (int)st.filter, gridP, blk, s);
         c->stats.samples += (uint64_t)w.W * w.H;
