@@ -207,6 +207,40 @@ int rtx_update_tile_samples(rtx_ctx* ctx);
 /* Overwrite SPP (after a cross-GPU sum of films rendered with shard_mode 2). */
 int rtx_set_spp(rtx_ctx* ctx, int spp);
 
+/* ---- one render over several GPUs (no reference counterpart: the reference's only parallelism is the std::thread
+ * tile queue of RTBase/Renderer.h:677-782, which is what the partitioning follows) ------------------------------------
+ *
+ * One process and one context per GPU, the scene uploaded to each; rtx_settings.shard_mode / shard_rank / shard_world
+ * say which tiles (1) or which samples (2) the context renders. The contexts meet through an rtx_collective: two
+ * in-place all-reduce (sum) functions over device memory, which either enqueue on `hip_stream` or are complete when
+ * they return; they return 0 or a negative RTX_ERR_* code. */
+typedef struct {
+    void* user;
+    int (*allreduce_sum_f32)(void* user, float* dev, size_t n, void* hip_stream);
+    int (*allreduce_sum_u32)(void* user, uint32_t* dev, size_t n, void* hip_stream);
+} rtx_collective;
+
+/* RCCL (the collectives library of ROCm; xGMI between the GPUs of a node) behind an rtx_collective. The library is
+ * loaded when one of these is first called; RTX_ERR_STATE if it cannot be found. rtx_rccl_unique_id: ncclGetUniqueId, to
+ * be called on one rank and handed to the others by the host (pipe, file, MPI ...); rtx_rccl_comm_create:
+ * ncclCommInitRank on the context's GPU, collective over all ranks; rtx_collective_rccl fills `out` for that
+ * communicator (user = the ncclComm_t, which a host that links RCCL itself may also pass directly). */
+int rtx_rccl_unique_id(char id[128]);
+int rtx_rccl_comm_create(rtx_ctx* ctx, void** nccl_comm, int world, int rank, const char id[128]);
+int rtx_rccl_comm_destroy(void* nccl_comm);
+int rtx_collective_rccl(rtx_collective* out, void* nccl_comm);
+
+/* Sum the film accumulators of all ranks in place; blocking. */
+int rtx_film_allreduce(rtx_ctx* ctx, const rtx_collective* coll);
+
+/* settings.total_spp GLOBAL samples per pixel, this context's share of them according to its shard settings, and
+ * the complete film with SPP = total_spp on every rank when it returns. With adaptive sampling the ranks meet once
+ * more, when the global sample count reaches initSPP: tile split - every rank computes the targets of its own tiles
+ * (complete pixels) and the tables are summed; sample split - the films are summed, every rank computes the same
+ * targets from the sum (calculateTileSamples, RTBase/Renderer.h:643-671) and carries on with its own partial film.
+ * shard_world 1 needs no collective (coll may be NULL) and equals rtx_render_passes(total_spp). Blocking. */
+int rtx_render_sharded(rtx_ctx* ctx, const rtx_collective* coll);
+
 /* RayTracer::createAOV, RTBase/Renderer.h:786-820: the three input planes of the denoiser, W*H*3
  * floats each, any pointer may be NULL. color = film / spp (per-tile spp once adaptive sampling
  * has taken over, :798-802); albedo = RayTracer::albedo (:553-565) and normal =

@@ -61,6 +61,15 @@ class Settings(C.Structure):
                 ("shard_mode", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32)]
 
 
+_ALLREDUCE_F32 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+_ALLREDUCE_U32 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class Collective(C.Structure):
+    """rtx_collective: two in-place all-reduce (sum) callbacks over device memory."""
+    _fields_ = [("user", C.c_void_p), ("allreduce_sum_f32", _ALLREDUCE_F32), ("allreduce_sum_u32", _ALLREDUCE_U32)]
+
+
 class Stats(C.Structure):
     _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("samples", C.c_uint64),
                 ("bvh2_nodes", C.c_uint32), ("bvh2_depth", C.c_uint32), ("bvh4_nodes", C.c_uint32),
@@ -174,6 +183,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         "rtx_timer_begin": [vp], "rtx_timer_end": [vp, C.POINTER(C.c_float)],
         "rtx_count_closest_work": [vp, vp, sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
         "rtx_count_render_work": [vp, C.c_int, C.POINTER(C.c_uint64)],
+        "rtx_rccl_unique_id": [C.c_char_p], "rtx_rccl_comm_create": [vp, C.POINTER(vp), C.c_int, C.c_int, C.c_char_p],
+        "rtx_rccl_comm_destroy": [vp], "rtx_collective_rccl": [C.POINTER(Collective), vp],
+        "rtx_film_allreduce": [vp, C.POINTER(Collective)], "rtx_render_sharded": [vp, C.POINTER(Collective)],
     }
     sig["rtx_host_bvh_build"] = [C.POINTER(SceneDesc), C.POINTER(vp)]
     sig["rtx_host_bvh_get"] = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), vp, vp, vp, C.POINTER(C.c_uint32),
@@ -332,6 +344,13 @@ class Core:
         a, b, g = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self._check(self.lib.rtx_count_closest_work(self.ctx, rays_ptr, n, C.byref(a), C.byref(b), C.byref(g)))
         return a.value, b.value, g.value
+
+    def render_sharded(self, collective: "Collective | None" = None):
+        """rtx_render_sharded: this context's share of settings.total_spp global samples, then the film sum."""
+        self._check(self.lib.rtx_render_sharded(self.ctx, C.byref(collective) if collective is not None else None))
+
+    def film_allreduce(self, collective: "Collective"):
+        self._check(self.lib.rtx_film_allreduce(self.ctx, C.byref(collective)))
 
     def count_render_work(self, n_passes: int = 1) -> dict:
         """n instrumented passes (the film advances as usual): rays, nodes visited, triangles tested."""

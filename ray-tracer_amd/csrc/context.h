@@ -43,7 +43,13 @@ struct PinBuf {
 
 struct WavefrontBuffers;   // path-tracing state (wavefront.h)
 
+// records the message rtx_last_error() returns on the calling thread and hands `code` back
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
 } // namespace rtx
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return rtx::fail(RTX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+#define CTX_TRY(ctx) do { if (!(ctx)) return rtx::fail(RTX_ERR_INVALID, "null context"); HIP_TRY(hipSetDevice((ctx)->device)); } while (0)
 
 struct rtx_ctx {
     int device = 0;

@@ -17,17 +17,16 @@
 
 using namespace rtx;
 
-namespace {
-
+namespace rtx {
 thread_local char g_err[512] = "";
-
 int fail(int code, const char* fmt, ...)
 {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
     return code;
 }
-#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(RTX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
-#define CTX_TRY(ctx) do { if (!(ctx)) return fail(RTX_ERR_INVALID, "null context"); HIP_TRY(hipSetDevice((ctx)->device)); } while (0)
+}
+
+namespace {
 
 template <class T>
 int upload(DevBuf& b, const std::vector<T>& v, hipStream_t s)

@@ -372,6 +372,9 @@ class RayTracer {                                                           // R
 public:
     Scene* scene = nullptr; GamesEngineeringBase::Window* canvas = nullptr; Film* film = nullptr; SETTINGS settings;
     std::vector<unsigned int> tileSamples; unsigned int totalTiles = 0, totalXTiles = 0; const unsigned int tileSize = 16;
+    // extension (the reference renders on one device): which share of a multi-GPU render this process takes; set before init().
+    // mode 1: the 16x16 tiles t with t % world == rank; mode 2: every pixel, the global samples s with s % world == rank
+    int shardMode = 0, shardRank = 0, shardWorld = 1;
 
     ~RayTracer() { delete film; }
     void init(Scene* scene_, GamesEngineeringBase::Window* canvas_, SETTINGS s)   // Renderer.h:69-87
@@ -388,7 +391,7 @@ public:
         r.use_mis = settings.useMis; r.can_hit_light = settings.canHitLight; r.adaptive_sampling = settings.adaptiveSampling;
         r.max_bounces = settings.maxBounces; r.init_spp = settings.initSPP; r.total_spp = settings.totalSPP;
         r.vpl_rays_per_tile = settings.vplRaysPerTile; r.num_threads = settings.numThreads; r.seed = settings.seed;
-        r.shard_mode = 0; r.shard_rank = 0; r.shard_world = 1;
+        r.shard_mode = shardWorld > 1 ? shardMode : 0; r.shard_rank = shardWorld > 1 ? shardRank : 0; r.shard_world = shardWorld > 1 ? shardWorld : 1;
         rtxCheck(rtx_set_settings(scene->ctx, &r), "RayTracer::init");
         rtxCheck(rtx_clear(scene->ctx), "RayTracer::init (clear)");
     }
@@ -398,6 +401,9 @@ public:
     void render() { renderMT(); }
     // extension: several passes per call let the core keep three of them in flight (~30 % more samples per second)
     void renderMT(int passes) { rtxCheck(rtx_render_passes(scene->ctx, passes), "RayTracer::renderMT"); rtxCheck(rtx_get_spp(scene->ctx, &film->SPP), "getSPP"); }
+    // extension: all totalSPP passes of a render that is split over the GPUs of `coll`'s communicator (this process's share of
+    // them; one meeting at initSPP for adaptive sampling, the film sum at the end); every rank ends with the complete film
+    void renderSharded(const rtx_collective* coll) { rtxCheck(rtx_render_sharded(scene->ctx, coll), "RayTracer::renderSharded"); rtxCheck(rtx_get_spp(scene->ctx, &film->SPP), "getSPP"); }
     int getSPP() const { return film->SPP; }                                                   // Renderer.h:856
     // pull the accumulated film and the tile targets to the host (film->film, tileSamples)
     void fetch() { rtxCheck(rtx_film_read(scene->ctx, &film->film[0].r, &film->SPP, tileSamples.data()), "RayTracer::fetch"); }

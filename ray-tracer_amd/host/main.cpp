@@ -3,18 +3,24 @@
 // renderMT() per progressive pass with the five console statistics, save the HDR when
 // totalSPP is reached. Flags of the reference: -scene, -outputFilename, -SPP
 // (RTBase/Main.cpp:104-115); added: -alg pt|lt|ir, -bounces N, -mis 0|1, -adaptive 0|1,
-// -seed N, -png file, -dumpFilm file (raw float sums), -dumpScene file, -digestScene dir, -digestImage file, -orbit degrees (yaw the view first), -batch N (passes per renderMT call), -device N, -quiet 1.
+// -seed N, -png file, -dumpFilm file (raw float sums), -dumpScene file, -digestScene dir, -digestImage file, -orbit degrees (yaw the view first), -batch N (passes per renderMT call), -device N, -quiet 1,
+// -gpus N -shard tiles|spp: one process per GPU (forked before anything touches a GPU; GPU r renders tiles or samples r mod N),
+// films combined by an RCCL all-reduce through the core's C ABI; rank 0 writes the outputs.
 //
 // -scene takes what the reference takes, a directory with scene.json + .gem meshes + textures
 // (GemScene.h), or an ".rtxs" dump (see SceneArrays.save in the Python package). -dumpScene file
 // writes the loaded scene as an .rtxs dump and exits without touching a GPU.
 #include <algorithm>
+#include <array>
 #include <cfloat>
 #include <cmath>
 #include <fstream>
 #include <iostream>
 #include <map>
 #include <unordered_map>
+
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "RayTracerHost.h"
 #include "GemScene.h"
@@ -143,7 +149,7 @@ static Scene* buildScene(const gem::SceneData& sd, int device)
 int main(int argc, char* argv[])
 {
     SETTINGS settings = createSettings();
-    std::string sceneName, filename = "render_GI.hdr", png, dump, dumpScene, digestDir, digestImage; int device = 0, batch = 1; bool quiet = false; float orbitDeg = 0.0f;
+    std::string sceneName, filename = "render_GI.hdr", png, dump, dumpScene, digestDir, digestImage, shard = "tiles"; int device = 0, batch = 1, gpus = 1; bool quiet = false; float orbitDeg = 0.0f;
     std::unordered_map<std::string, std::string> args;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -169,6 +175,8 @@ int main(int argc, char* argv[])
         else if (p.first == "-quiet") quiet = std::stoi(p.second) != 0;
         else if (p.first == "-orbit") orbitDeg = std::stof(p.second);
         else if (p.first == "-batch") batch = std::max(1, std::stoi(p.second));
+        else if (p.first == "-gpus") gpus = std::max(1, std::stoi(p.second));
+        else if (p.first == "-shard") shard = p.second;
         else std::cerr << "Warning: unknown flag '" << p.first << "'\n";
     }
     if (!digestImage.empty()) {   // width, height, channels and FNV-1a hash of the decoded pixels of one image file
@@ -186,6 +194,34 @@ int main(int argc, char* argv[])
         catch (const std::exception& e) { std::cerr << "error: " << e.what() << std::endl; return 1; }
     }
     if (sceneName.empty()) { std::cerr << "usage: rt_headless -scene <scene directory | file.rtxs> [-outputFilename out.hdr] [-SPP n] ...\n"; return 2; }
+    if (shard != "tiles" && shard != "spp") { std::cerr << "error: -shard takes tiles or spp\n"; return 2; }
+    // -gpus N: one process per GPU. The ranks are forked here, before this process has made any GPU call; rank 0 creates the
+    // RCCL id once its own GPU is up and sends it to the others through pipes that exist before the fork.
+    int rank = 0; std::vector<int> idPipes;        // rank 0: write ends towards ranks 1..N-1; other ranks: their read end
+    if (gpus > 1) {
+        std::vector<std::array<int, 2>> pipes((size_t)gpus);
+        for (int r = 1; r < gpus; r++) if (pipe(pipes[(size_t)r].data()) != 0) { std::perror("pipe"); return 1; }
+        std::vector<pid_t> kids;
+        bool child = false;
+        for (int r = 0; r < gpus && !child; r++) {
+            pid_t pid = fork();
+            if (pid < 0) { std::perror("fork"); return 1; }
+            if (pid == 0) { child = true; rank = r; } else kids.push_back(pid);
+        }
+        if (!child) {
+            for (int r = 1; r < gpus; r++) { close(pipes[(size_t)r][0]); close(pipes[(size_t)r][1]); }
+            int worst = 0;
+            for (pid_t k : kids) { int st = 0; waitpid(k, &st, 0); worst = std::max(worst, WIFEXITED(st) ? WEXITSTATUS(st) : 1); }
+            return worst;
+        }
+        for (int r = 1; r < gpus; r++) {
+            if (rank == 0) { close(pipes[(size_t)r][0]); idPipes.push_back(pipes[(size_t)r][1]); }
+            else if (r == rank) { close(pipes[(size_t)r][1]); idPipes.push_back(pipes[(size_t)r][0]); }
+            else { close(pipes[(size_t)r][0]); close(pipes[(size_t)r][1]); }
+        }
+        device += rank;
+        if (rank != 0) quiet = true;
+    }
     try {
         gem::SceneData data;
         std::cout << "Loading scene: " << sceneName << std::endl;
@@ -198,9 +234,26 @@ int main(int argc, char* argv[])
         GamesEngineeringBase::Window canvas;
         canvas.create((unsigned int)scene->camera.width, (unsigned int)scene->camera.height, "Tracer", 1.0f);
         RayTracer rt;
+        rt.shardMode = shard == "spp" || settings.algorithm == AL_LIGHT_TRACE ? 2 : 1;   // light-tracing splats land anywhere: samples, not tiles
+        rt.shardRank = rank; rt.shardWorld = gpus;
         rt.init(scene, &canvas, settings);
         GamesEngineeringBase::Timer timer; float totalTime = 0;
         bool completed = false;
+        if (gpus > 1) {
+            // the whole render in one call: the ranks meet only at initSPP (adaptive sampling) and for the final film sum
+            char id[128];
+            if (rank == 0) { rtxCheck(rtx_rccl_unique_id(id), "rtx_rccl_unique_id"); for (int fd : idPipes) if (write(fd, id, sizeof id) != (ssize_t)sizeof id) throw std::runtime_error("cannot send the RCCL id"); }
+            else if (read(idPipes.at(0), id, sizeof id) != (ssize_t)sizeof id) throw std::runtime_error("cannot receive the RCCL id");
+            void* comm = nullptr; rtx_collective coll;
+            rtxCheck(rtx_rccl_comm_create(scene->ctx, &comm, gpus, rank, id), "rtx_rccl_comm_create");
+            rtxCheck(rtx_collective_rccl(&coll, comm), "rtx_collective_rccl");
+            timer.reset();
+            rt.renderSharded(&coll);
+            totalTime = timer.dt();
+            rtxCheck(rtx_rccl_comm_destroy(comm), "rtx_rccl_comm_destroy");
+            completed = true;
+            if (rank == 0) rt.saveHDR(filename);
+        }
         while (!completed) {   // the body of the reference's frame loop, RTBase/Main.cpp:166-215
             timer.reset();
             if (batch > 1) rt.renderMT(std::min<int>(batch, std::max<int>(1, (int)settings.totalSPP - rt.getSPP())));
@@ -214,6 +267,7 @@ int main(int argc, char* argv[])
             }
             if ((int)settings.totalSPP <= rt.getSPP() && settings.drawMode == DM_ALGORITHM) { completed = true; rt.saveHDR(filename); }
         }
+        if (rank != 0) { delete scene; return 0; }      // every rank holds the complete film; rank 0 writes it
         rt.draw();
         if (!png.empty()) rt.savePNG(png);
         if (!dump.empty()) {
@@ -223,7 +277,7 @@ int main(int argc, char* argv[])
             o.write(reinterpret_cast<const char*>(rt.film->film), (std::streamsize)((size_t)rt.film->width * rt.film->height * sizeof(Colour)));
             o.write(reinterpret_cast<const char*>(rt.tileSamples.data()), (std::streamsize)(rt.tileSamples.size() * 4));
         }
-        std::cout << "Done: " << rt.getSPP() << " spp in " << totalTime << " s (" << rt.getSPP() / totalTime << " spp/s)" << std::endl;
+        std::cout << "Done: " << rt.getSPP() << " spp in " << totalTime << " s (" << rt.getSPP() / totalTime << " spp/s)" << (gpus > 1 ? " on " + std::to_string(gpus) + " GPUs, split by " + shard : std::string()) << std::endl;
         delete scene;
     } catch (const std::exception& e) { std::cerr << "error: " << e.what() << std::endl; return 1; }
     return 0;

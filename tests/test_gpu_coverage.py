@@ -325,3 +325,88 @@ def test_deep_caterpillar_tree_uses_the_global_stack_part(pkg, lib, core, orc, s
     seg = np.concatenate([rays["o"], (rays["o"] + rays["d"] * rs.uniform(1, 1e6, (n, 1))).astype(np.float32)], 1).astype(np.float32)
     assert np.array_equal(core.trace_visible(seg), osc.trace_visible(seg))
     osc.close()
+
+
+# ---- the native multi-GPU driver (rtx_render_sharded, RCCL behind the C ABI) -------------------------
+
+@pytest.mark.parametrize("mode", ["tiles", "spp"])
+def test_native_render_sharded_two_contexts_one_gpu(pkg, lib, core, scenes, mode):
+    """rtx_render_sharded — the driver a C++ host calls — with an rtx_collective whose two all-reduce callbacks
+    sum over two contexts of this process (two threads stand in for two ranks): same checks as for the Python
+    driver. What RCCL would do between GPUs is the only part replaced."""
+    import ctypes as C
+    import torch
+    mg = importlib.import_module("ray-tracer_amd.multigpu")
+    torch.cuda.set_device(0)
+    scene, cam = scenes.mixed_scene(32, (128, 64)), pkg.look_at(lib, width=128, height=72, **scenes.mixed_camera())
+    base = pkg.make_settings(total_spp=24, init_spp=6, adaptive_sampling=1, seed=47)
+    core.upload_scene(scene); core.set_camera(cam); core.set_settings(base); core.clear()
+    core.render_sharded(None)                      # one rank: no collective needed, equals render_passes(total_spp)
+    want, wspp, wtiles = core.film()
+    assert wspp == 24
+    world = 2
+    dist = _LocalDist(world, torch)
+    out, errs, keep = [None] * world, [], []
+
+    def run(rank):
+        try:
+            dist.local.rank = rank
+            c = pkg.Core(0, lib)
+
+            def reduce(typestr):
+                def f(user, dev, n, stream):
+                    try:
+                        c.synchronize()
+                        t = torch.as_tensor(mg._DevArray(dev, n, typestr), device=torch.device("cuda", 0))
+                        dist.all_reduce(t)
+                        torch.cuda.synchronize()
+                        return 0
+                    except Exception as e:          # never let an exception cross the C frames
+                        errs.append(e); dist.bar.abort()
+                        return -2
+                return f
+            coll = pkg.Collective(None, pkg._ALLREDUCE_F32(reduce("<f4")), pkg._ALLREDUCE_U32(reduce("<i4")))
+            keep.append(coll)
+            c.upload_scene(scene); c.set_camera(cam)
+            c.set_settings(mg.shard_settings(base, rank, world, mode)); c.clear()
+            c.render_sharded(coll)
+            out[rank] = c.film()
+            c.close()
+        except Exception as e:
+            errs.append(e)
+            dist.bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+    (f0, s0, t0), (f1, s1, t1) = out
+    assert s0 == s1 == 24
+    assert np.array_equal(f0, f1) and np.array_equal(t0, t1)
+    if mode == "tiles":
+        assert np.array_equal(t0, wtiles) and np.array_equal(f0, want)
+    else:
+        assert np.abs(t0.astype(np.int64) - wtiles.astype(np.int64)).max() <= 1
+        same = np.repeat(np.repeat((t0 == wtiles).reshape(5, 8), 16, 0), 16, 1)[:72, :128]
+        assert same.mean() > 0.8
+        assert np.allclose(f0 * same[..., None], want * same[..., None], rtol=2e-5, atol=1e-6)
+
+
+def test_rccl_collective_on_a_single_rank_communicator(pkg, lib, core, scenes):
+    """The RCCL plumbing itself (library loaded at run time, unique id, communicator on the context's GPU, in-place
+    all-reduce on the context's stream) with the one rank a one-GPU box allows: the film must come back unchanged."""
+    import ctypes as C
+    core.upload_scene(scenes.cornell_box("mixed"))
+    core.set_camera(pkg.look_at(lib, width=64, height=48, **scenes.cornell_camera()))
+    core.set_settings(pkg.make_settings(total_spp=2, seed=3)); core.clear(); core.render_passes(2)
+    before = core.film()[0]
+    ident = C.create_string_buffer(128)
+    rc = lib.rtx_rccl_unique_id(ident)
+    if rc:
+        pytest.skip("RCCL unavailable: " + lib.rtx_last_error().decode())
+    comm = C.c_void_p()
+    assert lib.rtx_rccl_comm_create(core.ctx, C.byref(comm), 1, 0, ident) == 0, lib.rtx_last_error()
+    coll = pkg.Collective()
+    assert lib.rtx_collective_rccl(C.byref(coll), comm) == 0
+    core.film_allreduce(coll)
+    assert np.array_equal(core.film()[0], before)
+    assert lib.rtx_rccl_comm_destroy(comm) == 0
