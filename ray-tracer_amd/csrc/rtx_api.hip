@@ -448,16 +448,6 @@ int rtx_trace_closest_device(rtx_ctx* c, const rtx_ray* rays, size_t n, rtx_hit*
         // A/B baseline: static assignment of rays to lanes (RTX_VARIANT=0)
         hipLaunchKernelGGL(k_closest_static, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, c->dscene, rays, (uint32_t)n, hits,
                            c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock));
-    } else if (c->variant >= 5) {
-        // two rays per lane (A/B harness)
-        uint32_t* wc = c->b_counters.as<uint32_t>() + kWorkSlotWords;
-        HIP_TRY(hipMemsetAsync(wc, 0, kWorkSlotWords * 4, c->stream));
-        if (c->spill_lanes < 2) { c->spill_lanes = 2; int rc = ensure_spill(c); if (rc) return rc; }
-        const uint32_t gb = (uint32_t)dyn_grid_for(c, n);
-#define RTX_AB2(V, R, S, L, W) if (c->variant == V) hipLaunchKernelGGL((k_closest_ab2<R, S, L, W>), dim3(gb), dim3(kBlock), 0, c->stream, c->dscene, rays, (uint32_t)n, hits, \
-                           c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), c->spill_entries, wc);
-        RTX_AB2(5, 20, 28, 8, 4) RTX_AB2(6, 20, 40, 8, 4) RTX_AB2(7, 32, 40, 8, 4) RTX_AB2(8, 20, 28, 6, 4) RTX_AB2(9, 20, 40, 6, 5)
-#undef RTX_AB2
     } else if (c->variant >= 2) {
         uint32_t* wc = c->b_counters.as<uint32_t>() + kWorkSlotWords;
         HIP_TRY(hipMemsetAsync(wc, 0, kWorkSlotWords * 4, c->stream));

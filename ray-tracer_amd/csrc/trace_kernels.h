@@ -4,7 +4,6 @@
 #include "context.h"
 #include "traverse.h"
 #include "traverse_dyn.h"
-#include "traverse_dyn2.h"
 
 namespace rtx {
 
@@ -98,17 +97,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, W
     ClosestPolicy pol{sc, rays, nullptr, hits};
     __shared__ TailShare<kBlock> ts;
     traverse_dyn<ClosestPolicy, kModeClosest, false, REFILL, kBlock, LDS_N, UNROLL, SCHED, SHARE>(sc, stk, n, work_counter, pol, nullptr, &ts);
-}
-
-// Two rays per lane (traverse_dyn2.h), schedules under test
-template <int REFILL, int SCHED, int LDS_N, int WAVES>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_closest_ab2(DeviceScene sc, const rtx_ray* __restrict__ rays, uint32_t n, rtx_hit* __restrict__ hits,
-                                                        uint2* spill, uint32_t spill_stride, uint32_t spill_slab_entries, uint32_t* work_counter)
-{
-    __shared__ unsigned long long lds[2 * kBlock * LDS_N];
-    ClosestPolicy pol{sc, rays, nullptr, hits};
-    __shared__ TailShare2<kBlock> ts;
-    traverse_dyn2<ClosestPolicy, kModeClosest, REFILL, kBlock, LDS_N, SCHED, 1>(sc, lds, spill, spill_stride, spill_slab_entries, n, work_counter, pol, &ts);
 }
 
 // ---- visibility: Scene::visible, RTBase/Scene.h:170-178 -> traverseVisible, Geometry.h:568-610 ----
