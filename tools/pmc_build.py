@@ -51,7 +51,7 @@ def main():
             total_bytes += per_pass * (v.get("hbm_bytes_per_launch") or 0)
             total_us += per_pass * v.get("duration_ns", 0) / 1e3
         out["pathtrace"] = {"kernels": kernels, "hbm_bytes_per_pass": int(total_bytes), "kernel_us_per_pass": round(total_us, 1),
-                            "source": f"profiles/{a.tag}_pmc_pathtrace_raw.json: RTX_PIPELINE=1 tools/pt_profile.py --single 0 --passes {a.passes} (mixed-material scene, 1920x1080, one pass in flight)"}
+                            "source": f"profiles/{a.tag}_pmc_pathtrace_raw.json: RTX_PIPELINE=1 tools/pt_profile.py --single 0 --passes 12 (4 warm-up + 12 passes of the mixed-material scene, 1920x1080, one pass in flight)"}
     json.dump(out, open(a.out, "w"), indent=1)
     print(json.dumps(out)[:600])
 
