@@ -596,6 +596,38 @@ __global__ __launch_bounds__(kBlock) void k_lt_splat(WfPtrs w, DeviceScene sc, u
     traverse_dyn<SplatPolicy, kModeAny, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, nullptr, &ts);
 }
 
+// The camera connections of one stage and the closest hits of the next in one launch (as k_pt_trace_mixed does for the
+// path tracer's shadow rays): items [0, n_closest) are the live light paths of `queue`, the others connection segments.
+struct LtMixedPolicy {
+    const DeviceScene& sc; const WfPtrs& w; const uint32_t* queue; uint32_t n_closest; int filter;
+    __device__ __forceinline__ void fetch(uint32_t k, float o[3], float d[3], float& maxT, bool& any) const
+    {
+        if (k < n_closest) {
+            const rtx_ray r = w.ray[queue[k]];
+            o[0] = r.o[0]; o[1] = r.o[1]; o[2] = r.o[2]; d[0] = r.d[0]; d[1] = r.d[1]; d[2] = r.d[2]; maxT = 0.0f; any = false;
+        } else { segment_to_ray(w.sseg + 6 * (size_t)(k - n_closest), o, d, maxT); any = true; }
+    }
+    __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool reached) const
+    {
+        if (k < n_closest) w.hit[queue[k]] = make_hit(sc, best);
+        else if (reached && best.pos == 0xFFFFFFFFu) {
+            const size_t j = k - n_closest;
+            film_splat(w.film, (int)w.W, (int)w.H, filter, w.sxy[2 * j], w.sxy[2 * j + 1], ldc(w.sval + 3 * j));
+        }
+    }
+    __device__ __forceinline__ void note(uint32_t, uint32_t, uint32_t) const {}
+};
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_lt_trace_mixed(WfPtrs w, DeviceScene sc, uint32_t closest_counter, uint32_t segment_counter,
+                                                           const uint32_t* __restrict__ queue, uint32_t work_index, int filter, uint2* spill, uint32_t spill_stride)
+{
+    __shared__ unsigned long long lds[kBlock * kLdsStack];
+    LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
+    const uint32_t n_closest = w.cnt[closest_counter], n_seg = w.cnt[segment_counter];
+    LtMixedPolicy pol{sc, w, queue, n_closest, filter};
+    __shared__ TailShare<kBlock> ts;
+    traverse_dyn<LtMixedPolicy, kModeMixed, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, n_closest + n_seg, w.cnt + work_index, pol, nullptr, &ts);
+}
+
 // ---- instant radiosity: RTBase/Renderer.h:124-302 -------------------------------------------
 
 __device__ __forceinline__ void vpl_store(const WfPtrs& w, uint32_t idx, V3 x, V3 n, C3 Le)
@@ -906,14 +938,28 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         c->stats.samples += (uint64_t)w.W * w.H;
     } else if (st.algorithm == RTX_AL_LIGHT_TRACE) {
         hipLaunchKernelGGL(k_lt_emit, gridP, blk, 0, s, w, dscene, c->dcam, pp);
-        hipLaunchKernelGGL(k_lt_splat, gridT, blk, 0, s, w, dscene, (uint32_t)(kShadowCounterBase + 95), (uint32_t)(kShadowWorkBase + 95 * kWorkSlotWords), (int)st.filter, spill, sstride);
         uint32_t* qin = w.qa; uint32_t* qout = w.qb;
-        for (uint32_t d = 0; d < st.max_bounces; d++) {
-            pp.depth = d;
-            closest(qin, d);
-            hipLaunchKernelGGL(k_lt_shade, gridQ, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
-            hipLaunchKernelGGL(k_lt_splat, gridT, blk, 0, s, w, dscene, (uint32_t)(kShadowCounterBase + d), (uint32_t)(kShadowWorkBase + d * kWorkSlotWords), (int)st.filter, spill, sstride);
-            std::swap(qin, qout);
+        if (c->merge_shadow && !cw && st.max_bounces > 0) {
+            // the connections of the light vertices ride with the closest hits of depth 0, those of depth d with the
+            // closest hits of depth d + 1; the last ones go alone
+            for (uint32_t d = 0; d < st.max_bounces; d++) {
+                pp.depth = d;
+                hipLaunchKernelGGL(k_lt_trace_mixed, gridT, blk, 0, s, w, dscene, d, (uint32_t)(kShadowCounterBase + (d == 0 ? 95u : d - 1u)), (const uint32_t*)qin,
+                                   (uint32_t)(kClosestWorkBase + d * kWorkSlotWords), (int)st.filter, spill, sstride);
+                hipLaunchKernelGGL(k_lt_shade, gridQ, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
+                std::swap(qin, qout);
+            }
+            const uint32_t last = st.max_bounces - 1u;
+            hipLaunchKernelGGL(k_lt_splat, gridT, blk, 0, s, w, dscene, (uint32_t)(kShadowCounterBase + last), (uint32_t)(kShadowWorkBase + last * kWorkSlotWords), (int)st.filter, spill, sstride);
+        } else {
+            hipLaunchKernelGGL(k_lt_splat, gridT, blk, 0, s, w, dscene, (uint32_t)(kShadowCounterBase + 95), (uint32_t)(kShadowWorkBase + 95 * kWorkSlotWords), (int)st.filter, spill, sstride);
+            for (uint32_t d = 0; d < st.max_bounces; d++) {
+                pp.depth = d;
+                closest(qin, d);
+                hipLaunchKernelGGL(k_lt_shade, gridQ, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
+                hipLaunchKernelGGL(k_lt_splat, gridT, blk, 0, s, w, dscene, (uint32_t)(kShadowCounterBase + d), (uint32_t)(kShadowWorkBase + d * kWorkSlotWords), (int)st.filter, spill, sstride);
+                std::swap(qin, qout);
+            }
         }
         c->stats.samples += (uint64_t)w.W * w.H;
     } else {
