@@ -229,6 +229,8 @@ int rtx_upload_scene(rtx_ctx* c, const rtx_scene_desc* d)
     ds.env_inv_w = h.env_w ? 1.0f / (float)h.env_w : 0.f; ds.env_inv_h = h.env_h ? 1.0f / (float)h.env_h : 0.f;
     ds.scene_radius = h.scene_radius;
     ds.spread_below = 32;
+    ds.fine_per_wave = 192;
+    if (const char* v = getenv("RTX_FINE")) ds.fine_per_wave = (uint32_t)std::max(0, std::min(4096, atoi(v)));   // tuning override
     if (const char* v = getenv("RTX_SPREAD")) ds.spread_below = (uint32_t)std::max(0, std::min(32, atoi(v)));   // tuning override
 
     // traversal stack: at most three pushes per wide level, or one pending node per binary

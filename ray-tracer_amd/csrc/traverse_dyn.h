@@ -30,7 +30,8 @@ namespace rtx {
 // launch.
 constexpr int kWorkSegments = 64;
 constexpr int kWorkStride = 32;
-constexpr int kWorkSlotWords = kWorkSegments * kWorkStride;
+constexpr int kWorkMaskCopies = 8;      // after the counters: kWorkMaskCopies lines with the "told dry" words (chunk counters, item counters)
+constexpr int kWorkSlotWords = (kWorkSegments + kWorkMaskCopies) * kWorkStride;
 
 // The chunk that counter `seg` hands out as its j-th: chunk j * kWorkSegments + c, where the eight
 // counters of one XCD (workgroup b runs on XCD b % 8 and draws from counter b % 64) own eight
@@ -101,8 +102,8 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
     // whole grid sweeps through the items on one front (neighbouring rays are in flight
     // together and find each other's nodes in the caches) while the fetch atomics are spread
     // over kWorkSegments addresses instead of queueing on one. A wave draws from the counter
-    // of its workgroup; when that one has run dry it looks at all counters at once (one
-    // coherent load per lane) and moves to one that still has chunks. Wave-uniform state.
+    // of its workgroup; when that one has run dry it moves to one that nobody has reported
+    // dry yet. Wave-uniform state.
     //
     // Small launches (fewer than half a wave of items per wave of the grid) are spread instead: chunks of 1 .. 32 items,
     // so that every wave of the grid gets some, a wave fetches again only when all its lanes are free, and the
@@ -110,6 +111,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
     // not limited by throughput but by the dependent node fetches of its longest rays, and the helpers walk
     // the pending subtrees of a ray side by side.
     uint32_t chunk = 64u, refill = (uint32_t)REFILL;
+    constexpr uint32_t GL = 4u, GM = (1u << GL) - 1u;      // the item counters hand out groups of 16 neighbouring items
     bool spread = false, eager = false;   // eager: most lanes are free, so pending children are handed to them after every level
     if constexpr (SHARE != 0) {
         const uint32_t waves = gridDim.x * (uint32_t)(BLOCK / 64);
@@ -120,9 +122,26 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
             ts->key[threadIdx.x] = pack_hit(best); ts->pending[threadIdx.x] = 0u; tail = true;
         }
     }
-    const uint32_t n_chunks = (n + chunk - 1u) / chunk;
+    // The end of the queue is handed out item by item. With chunks, a wave that finds the counters dry still has
+    // up to a chunk of unstarted items parked, another one none, and the launch ends with the unluckiest wave. So the
+    // last fine_per_wave items per wave of the grid (whole chunks before them) are drawn from a second set of
+    // counters (word 1 of every segment; groups of 16 items, interleaved over the counters), exactly as many as the wave has free
+    // lanes for: one atomic per refill instead of one per chunk, but only for that last part, and nothing is parked
+    // when the work runs out.
+    uint32_t n_coarse = n, fine_range = 0;             // items [0, n_coarse) go out in chunks; every counter then has fine_range positions of the rest
+    if (!spread && sc.fine_per_wave && n <= 0xFFFF0000u) {      // (beyond that the 32-bit item arithmetic below could wrap)
+        const unsigned long long want = (unsigned long long)gridDim.x * (uint32_t)(BLOCK / 64) * sc.fine_per_wave;
+        n_coarse = want >= n ? 0u : (uint32_t)((n - want) / 64u) * 64u;
+        fine_range = ((n - n_coarse + ((uint32_t)kWorkSegments << GL) - 1u) / ((uint32_t)kWorkSegments << GL)) << GL;
+    }
+    const uint32_t n_chunks = (n_coarse + chunk - 1u) / chunk;
     uint32_t seg = blockIdx.x % (uint32_t)kWorkSegments, loc_next = 0, loc_end = 0;
-    bool exhausted = false;
+    uint32_t hop = (blockIdx.x * (uint32_t)(BLOCK / 64) + (threadIdx.x >> 6)) * 2654435761u;   // wave-uniform
+    bool exhausted = false, fine = n_coarse == 0u && fine_range != 0u;
+    // counters of the current part that are known to be dry: those that never had a chunk, then what this wave finds out
+    unsigned long long dry_seen = fine ? 0ull : ~__ballot(work_chunk(0u, lane) < n_chunks);
+    if (!fine && dry_seen == ~0ull) { if (fine_range != 0u) { fine = true; dry_seen = 0ull; } else exhausted = true; }
+    if (!fine && !exhausted && ((dry_seen >> seg) & 1ull)) seg = nth_set_bit(~dry_seen, (hop >> 16) % (uint32_t)__popcll(~dry_seen));   // (a launch of a few chunks)
     for (;;) {
         if constexpr (SHARE) {
             if (tail && item != kNone) {
@@ -160,27 +179,43 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
         uint32_t n_idle = (uint32_t)__popcll(m);
         while (!exhausted && n_idle >= refill) {
             if (loc_next == loc_end) {
+                const uint32_t ask = fine ? n_idle : 1u;
                 uint32_t j = 0;
-                if (lane == 0) j = atomicAdd(work + seg * (uint32_t)kWorkStride, 1u);
+                if (lane == 0) j = atomicAdd(work + seg * (uint32_t)kWorkStride + (fine ? 1u : 0u), ask);
                 j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
                 // chunk index j * kWorkSegments + seg; j is far below 2^26 because n < 2^32
                 const uint32_t g = work_chunk(j, seg);
-                if (j >= (1u << 26) || g >= n_chunks) {
-                    // this counter is dry: which ones are not?
-                    const uint32_t cj = __hip_atomic_load(work + lane * (uint32_t)kWorkStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long live = __ballot(cj < (1u << 26) && work_chunk(cj, lane) < n_chunks);
-                    if (live == 0ull) { exhausted = true; continue; }
-                    // nearest live counter after this one, cyclically
-                    const unsigned long long rot = seg ? ((live >> seg) | (live << (64u - seg))) : live;
-                    seg = (seg + (uint32_t)__ffsll((long long)rot) - 1u) & 63u;
+                const bool dry = fine ? j >= fine_range : (j >= (1u << 26) || g >= n_chunks);
+                // The wave whose request crosses the end of a counter tells everybody (a bit per counter, one word per part,
+                // a copy per XCD): a wave that finds its counter dry then knows where not to ask. The counters themselves are
+                // never read: a load of a line that atomics are working on takes tens of microseconds when thousands of waves do it.
+                const bool last = fine ? (j < fine_range && j + ask >= fine_range) : (!dry && work_chunk(j + 1u, seg) >= n_chunks);
+                unsigned long long* told = (unsigned long long*)(work + (uint32_t)kWorkSegments * (uint32_t)kWorkStride) + (fine ? 1 : 0);
+                if (last && lane < (uint32_t)kWorkMaskCopies) atomicOr(told + lane * (uint32_t)(kWorkStride / 2), 1ull << seg);
+                if (last) dry_seen |= 1ull << seg;
+                if (dry) {
+                    dry_seen |= 1ull << seg;
+                    const unsigned long long mk = __hip_atomic_load(told + (blockIdx.x % (uint32_t)kWorkMaskCopies) * (uint32_t)(kWorkStride / 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long live = ~(dry_seen | mk);
+                    if (live == 0ull) {
+                        // this part of the queue is handed out
+                        if (!fine && fine_range != 0u) { fine = true; dry_seen = 0ull; seg = blockIdx.x % (uint32_t)kWorkSegments; } else exhausted = true;
+                        continue;
+                    }
+                    // a random live one: the waves of a dry counter must not all land on the same next one
+                    hop = hop * 1664525u + 1013904223u;
+                    seg = nth_set_bit(live, (hop >> 16) % (uint32_t)__popcll(live));
                     continue;
                 }
-                loc_next = g * chunk; loc_end = min(loc_next + chunk, n);
+                if (fine) { loc_next = j; loc_end = min(j + ask, fine_range); }
+                else { loc_next = g * chunk; loc_end = min(loc_next + chunk, n_coarse); }
             }
             const uint32_t take = min(n_idle, loc_end - loc_next);
             const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (cur == kDone && item == kNone && rank < take) {
-                const uint32_t k = loc_next + rank;
+            if (cur == kDone && item == kNone && rank < take && (!fine || ((((loc_next + rank) >> GL) * (uint32_t)kWorkSegments + seg) << GL | ((loc_next + rank) & GM)) < n - n_coarse)) {
+                // fine part: position x of counter seg is item x % 16 of that counter's (x / 16)-th group of 16, and the groups of the counters interleave
+                const uint32_t x = loc_next + rank;
+                const uint32_t k = fine ? n_coarse + ((((x >> GL) * (uint32_t)kWorkSegments + seg) << GL) | (x & GM)) : x;
                 float o[3], d[3];
                 if constexpr (MODE == kModeMixed) pol.fetch(k, o, d, maxT, any_lane); else pol.fetch(k, o, d, maxT);
                 ox = o[0]; oy = o[1]; oz = o[2]; dx = d[0]; dy = d[1]; dz = d[2];
