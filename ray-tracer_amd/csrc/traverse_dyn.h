@@ -195,7 +195,9 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
                 if (last) dry_seen |= 1ull << seg;
                 if (dry) {
                     dry_seen |= 1ull << seg;
-                    const unsigned long long mk = __hip_atomic_load(told + (blockIdx.x % (uint32_t)kWorkMaskCopies) * (uint32_t)(kWorkStride / 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // (lane 0's view for everybody: bits arrive while the lanes of one load are served, and the wave must agree on what it saw)
+                    unsigned long long mk = __hip_atomic_load(told + (blockIdx.x % (uint32_t)kWorkMaskCopies) * (uint32_t)(kWorkStride / 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    mk = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mk >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mk);
                     const unsigned long long live = ~(dry_seen | mk);
                     if (live == 0ull) {
                         // this part of the queue is handed out

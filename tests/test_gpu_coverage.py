@@ -410,3 +410,33 @@ def test_rccl_collective_on_a_single_rank_communicator(pkg, lib, core, scenes):
     core.film_allreduce(coll)
     assert np.array_equal(core.film()[0], before)
     assert lib.rtx_rccl_comm_destroy(comm) == 0
+
+
+# ---- many passes in flight, every way the work is handed out -----------------------------------
+
+@pytest.mark.parametrize("fine", ["0", None], ids=["chunks_only", "default"])
+def test_passes_in_flight_equal_one_pass_per_call(pkg, lib, core, scenes, fine, monkeypatch):
+    """Full-size Cornell stand-in (1024x1024: every launch fills the grid, rays of a few steps each, so the waves
+    ask for work all the time and meet at the end of every queue), 48 passes with three in flight against one pass
+    per call. With the end of the queues handed out in chunks only (RTX_FINE=0) a wave whose lanes disagreed on
+    which counters had been reported dry used to hang this within a few passes. The films must agree but for the
+    box-filter strays (a sample whose x + r rounds up into the next pixel is an atomic add on a pixel another
+    sample owns: summation order)."""
+    if fine is None: monkeypatch.delenv("RTX_FINE", raising=False)
+    else: monkeypatch.setenv("RTX_FINE", fine)
+    scene, cam = scenes.cornell_box("diffuse"), pkg.look_at(lib, width=1024, height=1024, **scenes.cornell_camera())
+    st = pkg.make_settings(total_spp=48, max_bounces=5, use_mis=1, seed=77)
+    films = []
+    for per_call in (48, 1):
+        c = pkg.Core(0, lib)                # the hand-out switch is read when a context is created
+        c.upload_scene(scene); c.set_camera(cam); c.set_settings(st); c.clear()
+        for _ in range(48 // per_call):
+            c.render_passes(per_call)
+        f, spp, _ = c.film()
+        assert spp == 48 and np.isfinite(f).all()
+        films.append(f / spp)
+        c.close()
+    a, b = films
+    differ = (np.abs(a - b) > 1e-5 * (1.0 + np.abs(b))).any(-1).mean()
+    print(f"pipelined vs one pass per call: {differ:.5%} of pixels differ, means {a.mean():.6f} / {b.mean():.6f}")
+    assert differ < 1e-3 and abs(a.mean() - b.mean()) < 1e-5 * b.mean()
