@@ -639,7 +639,7 @@ int rtx_count_render_work(rtx_ctx* c, int n_passes, uint64_t out[6])
     HIP_TRY(hipMemsetAsync(c->b_counters.p, 0, 4 * kWorkSlotWords, c->stream));
     if (c->spill_lanes < 2) { c->spill_lanes = 2; int rc = ensure_spill(c); if (rc) return rc; }
     for (int i = 0; i < 6; i++) out[i] = 0;
-    std::vector<uint32_t> q(2 * 96);
+    std::vector<uint32_t> q(2 * 96 * kQueueStride);
     c->count_work = true; c->passes_in_flight = 1;
     for (int i = 0; i < n_passes; i++) {
         const uint64_t before = c->stats.samples;
@@ -648,7 +648,7 @@ int rtx_count_render_work(rtx_ctx* c, int n_passes, uint64_t out[6])
         if (!rc && e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (rc || e != hipSuccess) { c->count_work = false; return fail(rc ? rc : RTX_ERR_HIP, "instrumented render pass failed: %s", hipGetErrorString(e)); }
         // queue lengths of the pass: live paths per depth (one closest-hit ray each), shadow / connection segments per depth
-        for (int d = 0; d < 96; d++) { out[0] += q[d]; out[1] += q[96 + d]; }
+        for (int d = 0; d < 96; d++) { out[0] += q[d * kQueueStride]; out[1] += q[(96 + d) * kQueueStride]; }
         out[4] += c->stats.samples - before;
     }
     c->count_work = false;

@@ -21,11 +21,14 @@ namespace rtx {
 
 constexpr uint32_t kFlagCanHitLight = 1u;   // emission counts at the next hit (Renderer.h:487,516)
 constexpr uint32_t kFlagStarted = 2u;       // slot carries a sample this pass
-// counter words, zeroed once per pass: [0,96) live-queue lengths per depth, [96,192) shadow /
-// connection queue lengths per depth, [256,352) and [352,448) the work counters of the
-// closest-hit and shadow-ray launches of each depth (dynamic ray fetch)
+// counter words, zeroed once per pass: queue lengths [0,96) live paths per depth, [96,192) shadow /
+// connection segments per depth, every one on a line of its own (a kernel reads the length of its input queue
+// while the workgroups that started earlier push onto its output queue with atomics, and a load of a line that
+// atomics are working on waits behind them); then the work-counter slots of the closest-hit and shadow-ray
+// launches of each depth (dynamic ray fetch)
 constexpr int kShadowCounterBase = 96;
-constexpr int kClosestWorkBase = 256;                                       // 96 work-counter slots of the closest-hit launches
+constexpr int kQueueStride = 32;                                            // queue length q lives in word q * kQueueStride: a 128-byte line of its own
+constexpr int kClosestWorkBase = 192 * kQueueStride;                        // 96 work-counter slots of the closest-hit launches
 constexpr int kShadowWorkBase = kClosestWorkBase + 96 * kWorkSlotWords;     // 96 slots of the shadow / splat launches
 constexpr int kCounterWords = kShadowWorkBase + 96 * kWorkSlotWords;
 
@@ -246,13 +249,13 @@ __global__ __launch_bounds__(1024) void k_tile_offsets(WfPtrs w, PassParams pp)
             }
         }
     }
-    if (threadIdx.x == 1023u) w.cnt[0] = s_part[1023];
+    if (threadIdx.x == 1023u) w.cnt[(0) * kQueueStride] = s_part[1023];
 }
 
 // One depth of RayTracer::pathTrace, RTBase/Renderer.h:476-526, for every live path.
 __global__ __launch_bounds__(kBlock) void k_pt_shade(WfPtrs w, DeviceScene sc, PassParams pp, const uint32_t* __restrict__ qin, uint32_t* qout)
 {
-    const uint32_t n = w.cnt[pp.depth];
+    const uint32_t n = w.cnt[(pp.depth) * kQueueStride];
     const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
     for (uint32_t it = 0; it < rounds; it++) {
         const uint32_t i = it * gridDim.x * kBlock + global_thread();
@@ -297,12 +300,12 @@ __global__ __launch_bounds__(kBlock) void k_pt_shade(WfPtrs w, DeviceScene sc, P
                 st3(w.L + 3 * slot, L);
             }
         }
-        uint32_t qs = queue_slot(shadow, &w.cnt[kShadowCounterBase + pp.depth]);
+        uint32_t qs = queue_slot(shadow, &w.cnt[(kShadowCounterBase + pp.depth) * kQueueStride]);
         if (shadow) {
             float* s = w.sseg + 6 * (size_t)qs; s[0] = sx.x; s[1] = sx.y; s[2] = sx.z; s[3] = p2.x; s[4] = p2.y; s[5] = p2.z;
             st3(w.sval + 3 * (size_t)qs, sval); w.spath[qs] = slot;
         }
-        uint32_t qc = queue_slot(cont, &w.cnt[pp.depth + 1]);
+        uint32_t qc = queue_slot(cont, &w.cnt[(pp.depth + 1) * kQueueStride]);
         if (cont) qout[qc] = slot;
     }
 }
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_accumulate(WfPtrs w, DeviceSc
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     ShadowAccumulatePolicy pol{w};
     __shared__ TailShare<kBlock> ts;
-    traverse_dyn<ShadowAccumulatePolicy, kModeAny, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, COUNT ? 0 : kShare>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, counters, &ts);
+    traverse_dyn<ShadowAccumulatePolicy, kModeAny, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, COUNT ? 0 : kShare>(sc, stk, w.cnt[(counter_index) * kQueueStride], w.cnt + work_index, pol, counters, &ts);
 }
 // closest hits of a queue with the work counters on (the plain policy's note() keeps per-ray counts in the hit record,
 // which a render pass needs intact)
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
 {
     __shared__ unsigned long long lds[kBlock * kLdsStack];
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
-    const uint32_t n_closest = w.cnt[depth], n_shadow = w.cnt[kShadowCounterBase + depth - 1];
+    const uint32_t n_closest = w.cnt[(depth) * kQueueStride], n_shadow = w.cnt[(kShadowCounterBase + depth - 1) * kQueueStride];
     PtMixedPolicy pol{sc, w, queue, n_closest};
     __shared__ TailShare<kBlock> ts;
     traverse_dyn<PtMixedPolicy, kModeMixed, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, COUNT ? 0 : kShare>(sc, stk, n_closest + n_shadow, w.cnt + work_index, pol, counters, &ts);
@@ -427,7 +430,7 @@ inline void launch_film_accumulate(const WfPtrs& w, int filter, dim3 grid, dim3 
 // ---- draw modes: RayTracer::direct / albedo / viewNormals, RTBase/Renderer.h:536-575 -------
 __global__ __launch_bounds__(kBlock) void k_dm_shade(WfPtrs w, DeviceScene sc, PassParams pp)
 {
-    const uint32_t n = w.cnt[0];
+    const uint32_t n = w.cnt[(0) * kQueueStride];
     const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
     for (uint32_t it = 0; it < rounds; it++) {
         const uint32_t i = it * gridDim.x * kBlock + global_thread();
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(kBlock) void k_dm_shade(WfPtrs w, DeviceScene sc, P
             } else if (pp.st.draw_mode != RTX_DM_NORMALS) L = background_evaluate(sc, d);
             st3(w.L + 3 * slot, L);
         }
-        uint32_t qs = queue_slot(shadow, &w.cnt[kShadowCounterBase]);
+        uint32_t qs = queue_slot(shadow, &w.cnt[(kShadowCounterBase) * kQueueStride]);
         if (shadow) {
             float* s = w.sseg + 6 * (size_t)qs; s[0] = sx.x; s[1] = sx.y; s[2] = sx.z; s[3] = p2.x; s[4] = p2.y; s[5] = p2.z;
             st3(w.sval + 3 * (size_t)qs, sval); w.spath[qs] = slot;
@@ -498,7 +501,7 @@ __device__ __forceinline__ bool connect_request(const CameraDev& cam, V3 p, V3 n
 
 __device__ __forceinline__ void push_connection(const WfPtrs& w, bool want, uint32_t counter, V3 p, const CameraDev& cam, float x, float y, C3 value)
 {
-    uint32_t qs = queue_slot(want, &w.cnt[counter]);
+    uint32_t qs = queue_slot(want, &w.cnt[(counter) * kQueueStride]);
     if (want) {
         float* s = w.sseg + 6 * (size_t)qs; s[0] = p.x; s[1] = p.y; s[2] = p.z; s[3] = cam.origin[0]; s[4] = cam.origin[1]; s[5] = cam.origin[2];
         st3(w.sval + 3 * (size_t)qs, value); w.sxy[2 * (size_t)qs] = x; w.sxy[2 * (size_t)qs + 1] = y;
@@ -534,14 +537,14 @@ __global__ __launch_bounds__(kBlock) void k_lt_emit(WfPtrs w, DeviceScene sc, Ca
     push_connection(w, conn, kShadowCounterBase + 95, p, cam, fx, fy, cval);
     // lightTracePath returns at once when maxBounces == 0 (Renderer.h:339)
     bool live = active && pp.st.max_bounces > 0;
-    uint32_t q = queue_slot(live, &w.cnt[0]);
+    uint32_t q = queue_slot(live, &w.cnt[(0) * kQueueStride]);
     if (live) w.qa[q] = slot;
 }
 
 // One depth of RayTracer::lightTracePath, RTBase/Renderer.h:336-377
 __global__ __launch_bounds__(kBlock) void k_lt_shade(WfPtrs w, DeviceScene sc, CameraDev cam, PassParams pp, const uint32_t* __restrict__ qin, uint32_t* qout)
 {
-    const uint32_t n = w.cnt[pp.depth];
+    const uint32_t n = w.cnt[(pp.depth) * kQueueStride];
     const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
     for (uint32_t it = 0; it < rounds; it++) {
         const uint32_t i = it * gridDim.x * kBlock + global_thread();
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(kBlock) void k_lt_shade(WfPtrs w, DeviceScene sc, C
             }
         }
         push_connection(w, conn, kShadowCounterBase + pp.depth, hp, cam, fx, fy, cval);
-        uint32_t qc = queue_slot(cont, &w.cnt[pp.depth + 1]);
+        uint32_t qc = queue_slot(cont, &w.cnt[(pp.depth + 1) * kQueueStride]);
         if (cont) qout[qc] = slot;
     }
 }
@@ -593,7 +596,7 @@ __global__ __launch_bounds__(kBlock) void k_lt_splat(WfPtrs w, DeviceScene sc, u
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     SplatPolicy pol{w, filter};
     __shared__ TailShare<kBlock> ts;
-    traverse_dyn<SplatPolicy, kModeAny, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, w.cnt[counter_index], w.cnt + work_index, pol, nullptr, &ts);
+    traverse_dyn<SplatPolicy, kModeAny, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, w.cnt[(counter_index) * kQueueStride], w.cnt + work_index, pol, nullptr, &ts);
 }
 
 // The camera connections of one stage and the closest hits of the next in one launch (as k_pt_trace_mixed does for the
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
 {
     __shared__ unsigned long long lds[kBlock * kLdsStack];
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
-    const uint32_t n_closest = w.cnt[closest_counter], n_seg = w.cnt[segment_counter];
+    const uint32_t n_closest = w.cnt[(closest_counter) * kQueueStride], n_seg = w.cnt[(segment_counter) * kQueueStride];
     LtMixedPolicy pol{sc, w, queue, n_closest, filter};
     __shared__ TailShare<kBlock> ts;
     traverse_dyn<LtMixedPolicy, kModeMixed, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, n_closest + n_seg, w.cnt + work_index, pol, nullptr, &ts);
@@ -658,14 +661,14 @@ __global__ __launch_bounds__(kBlock) void k_vpl_emit(WfPtrs w, DeviceScene sc, P
         w.key[j] = rng.key; w.dim[j] = rng.dim;
         live = pp.st.max_bounces > 0;
     }
-    uint32_t q = queue_slot(live, &w.cnt[0]);
+    uint32_t q = queue_slot(live, &w.cnt[(0) * kQueueStride]);
     if (live) w.qa[q] = j;
 }
 
 // One depth of RayTracer::VPLTracePath, RTBase/Renderer.h:124-168
 __global__ __launch_bounds__(kBlock) void k_vpl_shade(WfPtrs w, DeviceScene sc, PassParams pp, const uint32_t* __restrict__ qin, uint32_t* qout)
 {
-    const uint32_t n = w.cnt[pp.depth];
+    const uint32_t n = w.cnt[(pp.depth) * kQueueStride];
     const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
     for (uint32_t it = 0; it < rounds; it++) {
         const uint32_t i = it * gridDim.x * kBlock + global_thread();
@@ -693,7 +696,7 @@ __global__ __launch_bounds__(kBlock) void k_vpl_shade(WfPtrs w, DeviceScene sc, 
                 }
             }
         }
-        uint32_t qc = queue_slot(cont, &w.cnt[pp.depth + 1]);
+        uint32_t qc = queue_slot(cont, &w.cnt[(pp.depth + 1) * kQueueStride]);
         if (cont) qout[qc] = j;
     }
 }
@@ -713,7 +716,7 @@ __global__ __launch_bounds__(kBlock) void k_ir_gather(WfPtrs w, DeviceScene sc, 
 {
     __shared__ unsigned long long lds[kBlock * kLdsStack];
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
-    const uint32_t n = w.cnt[0];
+    const uint32_t n = w.cnt[(0) * kQueueStride];
     const uint32_t total = *w.vpl_total;
     for (uint32_t i = global_thread(); i < n; i += gridDim.x * kBlock) {
         const uint32_t slot = w.qa[i];
@@ -877,9 +880,9 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
     const bool cw = c->count_work;                       // instrumented kernels (rtx_count_render_work)
     unsigned long long* ctr = cw ? c->b_counters.as<unsigned long long>() : nullptr;
     auto closest = [&](const uint32_t* queue, uint32_t counter) {
-        if (cw) hipLaunchKernelGGL(k_closest_counted, gridT, blk, 0, s, dscene, (const rtx_ray*)w.ray, queue, (const uint32_t*)(w.cnt + counter), w.hit, spill, sstride,
+        if (cw) hipLaunchKernelGGL(k_closest_counted, gridT, blk, 0, s, dscene, (const rtx_ray*)w.ray, queue, (const uint32_t*)(w.cnt + counter * kQueueStride), w.hit, spill, sstride,
                                    w.cnt + kClosestWorkBase + counter * kWorkSlotWords, ctr);
-        else hipLaunchKernelGGL(k_closest<false>, gridT, blk, 0, s, dscene, (const rtx_ray*)w.ray, queue, 0u, (const uint32_t*)(w.cnt + counter), w.hit, spill, sstride,
+        else hipLaunchKernelGGL(k_closest<false>, gridT, blk, 0, s, dscene, (const rtx_ray*)w.ray, queue, 0u, (const uint32_t*)(w.cnt + counter * kQueueStride), w.hit, spill, sstride,
                            w.cnt + kClosestWorkBase + counter * kWorkSlotWords, (unsigned long long*)nullptr);
     };
     auto shadow = [&](hipStream_t on, uint32_t counter_index, uint32_t work_index, uint2* stacks) {
