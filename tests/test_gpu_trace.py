@@ -233,6 +233,33 @@ def test_ragged_batch_sizes_of_the_dynamic_fetch(pkg, lib, core, orc, scenes):
     osc.close()
 
 
+@pytest.mark.parametrize("fine", [None, "0", "48", "4096"], ids=["default", "chunks_only", "48_per_wave", "everything_item_by_item"])
+def test_hand_out_boundaries(pkg, lib, orc, scenes, fine, monkeypatch):
+    """The work hand-out changes its way with the size of a launch (5 120 waves on the device): below 32 rays per
+    wave it is spread thin, the last 192 rays per wave (RTX_FINE overrides) go out item by item and whole chunks of
+    64 before them. Sizes on both sides of every boundary, for several shares of the item-by-item part: each ray is
+    traced exactly once (hits equal the oracle's, ray by ray)."""
+    if fine is None: monkeypatch.delenv("RTX_FINE", raising=False)
+    else: monkeypatch.setenv("RTX_FINE", fine)
+    c = pkg.Core(0, lib)                      # the switch is read when a context is created
+    sc = scenes.soup(5000, seed=37, size=0.05)
+    c.upload_scene(sc)
+    osc = orc.scene(sc)
+    big = _rand_rays(pkg, 1_048_576 + 77, 79)
+    want = osc.trace_closest(big, threads=8)
+    per_wave = 192 if fine is None else int(fine)
+    sizes = {1, 64, 20_479, 20_481, 163_839, 163_840, 163_841, 300_000, 1_048_576, 1_048_576 + 77}
+    for edge in (5120 * per_wave, 5120 * per_wave + 64 * 64):      # where whole chunks start to exist / every counter has one
+        sizes |= {n for n in (edge - 1, edge, edge + 1, edge + 65) if 0 < n <= len(big)}
+    for n in sorted(sizes):
+        _assert_hits_equal(c.trace_closest(big[:n]), want[:n])
+    seg = np.random.RandomState(6).uniform(-1.1, 1.1, (400_003, 6)).astype(np.float32)
+    vis = osc.trace_visible(seg, threads=8)
+    for n in (163_841, 400_003):
+        assert np.array_equal(c.trace_visible(seg[:n]), vis[:n])
+    osc.close(); c.close()
+
+
 @pytest.mark.parametrize("seed,n_tris,size", [(101, 30_000, 0.02), (102, 8_000, 0.3), (103, 60_000, 0.05), (104, 500, 1.0)])
 def test_randomised_soups_closest_and_visible(pkg, lib, core, orc, scenes, seed, n_tris, size):
     """Different triangle sizes change how heavy-tailed the per-ray cost is (large triangles: deep
