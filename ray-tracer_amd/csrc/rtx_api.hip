@@ -456,7 +456,7 @@ int rtx_trace_closest_device(rtx_ctx* c, const rtx_ray* rays, size_t n, rtx_hit*
         const uint32_t gb = (uint32_t)dyn_grid_for(c, n);
 #define RTX_AB(V, R, U, S, L, W, SH) if (c->variant == V) hipLaunchKernelGGL((k_closest_ab<R, U, S, L, W, SH>), dim3(gb), dim3(kBlock), 0, c->stream, c->dscene, rays, \
                            (uint32_t)n, hits, c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), wc);
-        RTX_AB(2, 20, 4, 28, 12, 4, 0) RTX_AB(3, 16, 4, 24, 12, 4, 1) RTX_AB(4, 24, 4, 32, 12, 4, 1)   // no tail sharing; neighbours of the default (20 idle lanes to refill, 28 leaf lanes to stop descending)
+        RTX_AB(2, 20, 4, 28, 12, 4, 0) RTX_AB(3, 16, 4, 24, 12, 4, 1) RTX_AB(4, 24, 4, 32, 12, 4, 1)  // no tail sharing; neighbours of the default (20 idle lanes to refill, 28 leaf lanes to stop descending)
 #undef RTX_AB
     } else {
         uint32_t* wc = c->b_counters.as<uint32_t>() + kWorkSlotWords;

@@ -11,6 +11,8 @@ constexpr float kEpsilon = 0.001f;    // EPSILON, RTBase/Geometry.h:54
 constexpr int kRefill = 20;           // idle lanes that trigger a fetch of new rays
 constexpr int kTriUnroll = 4;         // leaf triangles whose loads are issued together
 constexpr int kLeafLanes = 28;        // the wave stops descending and tests triangles once this many lanes hold a leaf
+// the closest-hit kernel on its own (no visibility rays mixed in) does 2-3 % better with later refills and longer descents
+constexpr int kRefillClosest = 24, kLeafLanesClosest = 36;
 constexpr int kShare = 1;             // idle lanes share the pending subtrees of busy ones once the work counters are dry
 
 __device__ __forceinline__ uint32_t global_thread() { return blockIdx.x * kBlock + threadIdx.x; }
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(kBlock) void k_closest(DeviceScene sc, const rtx_ra
     ClosestPolicy pol{sc, rays, queue, hits};
     // the instrumented pass counts what one lane per ray visits, without helpers' speculative work
     __shared__ TailShare<kBlock> ts;
-    traverse_dyn<ClosestPolicy, kModeClosest, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, COUNT ? 0 : kShare>(sc, stk, n_dev ? *n_dev : n_host, work_counter, pol, counters, &ts);
+    traverse_dyn<ClosestPolicy, kModeClosest, COUNT, kRefillClosest, kBlock, kLdsStack, kTriUnroll, kLeafLanesClosest, COUNT ? 0 : kShare>(sc, stk, n_dev ? *n_dev : n_host, work_counter, pol, counters, &ts);
 }
 
 // Schedules under test (A/B harness only)

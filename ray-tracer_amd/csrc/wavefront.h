@@ -349,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void k_closest_counted(DeviceScene sc, cons
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     ClosestQuietPolicy pol{{sc, rays, queue, hits}};
     __shared__ TailShare<kBlock> ts;
-    traverse_dyn<ClosestQuietPolicy, kModeClosest, true, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, 0>(sc, stk, *n_dev, work_counter, pol, counters, &ts);
+    traverse_dyn<ClosestQuietPolicy, kModeClosest, true, kRefillClosest, kBlock, kLdsStack, kTriUnroll, kLeafLanesClosest, 0>(sc, stk, *n_dev, work_counter, pol, counters, &ts);
 }
 
 // The shadow rays of depth d - 1 and the closest-hit rays of depth d in ONE launch: neither depends on the other
