@@ -440,3 +440,23 @@ def test_passes_in_flight_equal_one_pass_per_call(pkg, lib, core, scenes, fine, 
     differ = (np.abs(a - b) > 1e-5 * (1.0 + np.abs(b))).any(-1).mean()
     print(f"pipelined vs one pass per call: {differ:.5%} of pixels differ, means {a.mean():.6f} / {b.mean():.6f}")
     assert differ < 1e-3 and abs(a.mean() - b.mean()) < 1e-5 * b.mean()
+
+
+# ---- a sample whose radiance is not a number is the reference's own result ---------------------
+
+def test_non_finite_sample_is_the_oracles(pkg, lib, core, orc, scenes):
+    """Sample 87 of seed 1007 of the 1080p mixed-material scene is NaN in exactly one pixel (found by
+    tools/stress_passes.py): the reference's arithmetic divides by a pdf of zero there, so the restatement of it
+    does too. The device must put its NaN in that pixel and nowhere else, and agree on the rest of the pass."""
+    st, osc = _setup(pkg, lib, core, orc, scenes.mixed_scene(128), scenes.mixed_camera(), 1920, 1080, seed=1007, total_spp=1 << 20, max_bounces=5, use_mis=1)
+    r = osc.renderer(st, threads=8, counter_rng=True)
+    r.film_write(np.zeros((1080, 1920, 3), np.float32), 86)
+    core.set_spp(86)
+    core.render_passes(1); r.render_passes(1)
+    (g, gs, _), (o, os_, _) = core.film(), r.film()
+    assert gs == os_ == 87
+    bad_g, bad_o = ~np.isfinite(g).all(-1), ~np.isfinite(o).all(-1)
+    assert np.argwhere(bad_o).tolist() == [[735, 1036]], "the oracle's non-finite pixels moved: the fixture of this test is stale"
+    assert np.array_equal(bad_g, bad_o)
+    _assert_films_match(g, o, "pass 87 of seed 1007")
+    osc.close()
