@@ -305,6 +305,9 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
                     // four consecutive 36-byte records are 144 bytes = nine 16-byte loads instead of twelve
                     // (4-byte aligned; records past the leaf's end are loaded but not tested, the array is padded)
                     const TriQuad Q = *(const TriQuad*)(sc.tris + first + k);
+                    // the first triangle's third vertex is only read once its determinant has passed, and the compiler would
+                    // move its load there: a second memory round trip in every triangle phase. Ask for it here, with the others.
+                    asm volatile("" :: "v"(Q.f[6]), "v"(Q.f[7]), "v"(Q.f[8]));
 #pragma unroll
                     for (int j = 0; j < 4; j++)
 #pragma unroll
