@@ -267,9 +267,19 @@ __device__ __forceinline__ uint32_t step_inner(const DeviceScene& sc, LaneStack<
 {
     // 32-bit byte offset from the (wave-uniform) array base: the load then takes a scalar base and one
     // vector offset register instead of a 64-bit address computed per lane (node indices stay below 2^25)
-    const float4* np = (const float4*)((const char*)sc.nodes4 + (uint32_t)(cur << 7));
-    const float4 lox = np[0], loy = np[1], loz = np[2], hix = np[3], hiy = np[4], hiz = np[5];
-    const float4 cf = np[6];
+    // The near plane of an axis is the low one for a ray that travels up that axis and the high one otherwise, so the
+    // lane loads "near" and "far" planes by address instead of loading low and high and taking minima and maxima:
+    // (near - o) * inv <= (far - o) * inv holds in floating point too (subtraction and multiplication by a finite
+    // reciprocal of one sign are monotone), so tentry and texit are the same numbers as the reference's
+    // min / max of the two products, 24 instructions per node fewer.
+    // 32-bit byte offsets from the (wave-uniform) array base: the loads then take a scalar base and one vector offset
+    // register instead of a 64-bit address computed per lane (node indices stay below 2^25)
+    const char* nodes = (const char*)sc.nodes4;
+    const uint32_t b = cur << 7;
+    const uint32_t nx = ix < 0.0f ? 48u : 0u, ny = iy < 0.0f ? 64u : 16u, nz = iz < 0.0f ? 80u : 32u;
+    const float4 nearx = *(const float4*)(nodes + (b | nx)), neary = *(const float4*)(nodes + (b | ny)), nearz = *(const float4*)(nodes + (b | nz));
+    const float4 farx = *(const float4*)(nodes + (b | (nx ^ 48u))), fary = *(const float4*)(nodes + (b | (ny ^ 80u))), farz = *(const float4*)(nodes + (b | (nz ^ 112u)));
+    const float4 cf = *(const float4*)(nodes + (b | 96u));
     if (COUNT) cnt->nodes++;
     const uint32_t ref[4] = {__float_as_uint(cf.x), __float_as_uint(cf.y), __float_as_uint(cf.z), __float_as_uint(cf.w)};
     // all four child references are needed whatever the boxes say: tested up front (and combined
@@ -279,7 +289,7 @@ __device__ __forceinline__ uint32_t step_inner(const DeviceScene& sc, LaneStack<
     // scalar subtract / multiply on purpose: the packed two-float forms cost more issue time than two scalar
     // instructions on this hardware (the library is also built without SLP vectorisation for that reason)
     const float O[3] = {ox, oy, oz}, I[3] = {ix, iy, iz};
-    const float4 lo4[3] = {lox, loy, loz}, hi4[3] = {hix, hiy, hiz};
+    const float4 lo4[3] = {nearx, neary, nearz}, hi4[3] = {farx, fary, farz};
     float t0[3][4], t1[3][4];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
@@ -290,8 +300,8 @@ __device__ __forceinline__ uint32_t step_inner(const DeviceScene& sc, LaneStack<
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         // no NaN can occur here (finite reciprocals), so plain min/max equal the reference's selects
-        float tentry = fmaxf(fmaxf(fminf(t0[0][c], t1[0][c]), fminf(t0[1][c], t1[1][c])), fminf(t0[2][c], t1[2][c]));
-        float texit = fminf(fminf(fmaxf(t0[0][c], t1[0][c]), fmaxf(t0[1][c], t1[1][c])), fmaxf(t0[2][c], t1[2][c]));
+        float tentry = fmaxf(fmaxf(t0[0][c], t0[1][c]), t0[2][c]);
+        float texit = fminf(fminf(t1[0][c], t1[1][c]), t1[2][c]);
         const bool hit = valid[c] & !(tentry > texit || texit < 0) & !(tentry > bound);
         key[c] = hit ? tentry : FLT_MAX;
         kref[c] = hit ? ref[c] : kEmptySlot;
