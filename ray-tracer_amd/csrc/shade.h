@@ -334,6 +334,11 @@ RTX_DI void shading_data(const DeviceScene& sc, const rtx_hit& h, V3 o, V3 d, Sh
     sd.tu = t.uv0[0] * h.alpha + t.uv1[0] * h.beta + t.uv2[0] * h.gamma;
     sd.tv = t.uv0[1] * h.alpha + t.uv1[1] * h.beta + t.uv2[1] * h.gamma;
     sd.mat = &sc.materials[t.material];
+    {   // the material fields every path reads (BSDF type, texture, light flag, two-sidedness), fetched together: left
+        // alone the compiler loads each where it is first used, one dependent round trip after the other
+        const MaterialDev& m = *sd.mat;
+        asm volatile("" :: "v"(m.type), "v"(m.tex_offset), "v"(m.tex_w), "v"(m.tex_h), "v"(m.is_light), "v"(m.two_sided));
+    }
     sd.wo = -d;
     if (isTwoSided(*sd.mat)) {
         if (dot(sd.wo, sd.sNormal) < 0) sd.sNormal = -sd.sNormal;

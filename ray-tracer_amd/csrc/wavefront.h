@@ -265,13 +265,17 @@ __global__ __launch_bounds__(kBlock) void k_pt_shade(WfPtrs w, DeviceScene sc, P
             const rtx_hit h = w.hit[slot]; const rtx_ray r = w.ray[slot];
             C3 T = ldc(w.T + 3 * slot); C3 L = ldc(w.L + 3 * slot);
             const uint32_t flags = w.flags[slot]; const float misPdf = w.mis[slot];
+            const uint32_t rkey = w.key[slot], rdim = w.dim[slot];
+            // the whole path state in one round trip: without this the compiler loads each piece where it is first
+            // read, behind the triangle record, the material and the texture, one dependent round trip each
+            asm volatile("" :: "v"(T.r), "v"(T.g), "v"(T.b), "v"(L.r), "v"(L.g), "v"(L.b), "v"(flags), "v"(misPdf), "v"(rkey), "v"(rdim));
             const V3 o = ld3(r.o), d = ld3(r.d);
             if (h.t < FLT_MAX) {
                 Shading sd; shading_data(sc, h, o, d, sd);
                 if (sd.mat->is_light) {
                     if (flags & kFlagCanHitLight) { L = L + T * ldc(sd.mat->emission); st3(w.L + 3 * slot, L); }
                 } else {
-                    Rng rng; rng.key = w.key[slot]; rng.dim = w.dim[slot];
+                    Rng rng; rng.key = rkey; rng.dim = rdim;
                     C3 dv;
                     if (direct_request(sc, sd, rng, pp.st.use_mis != 0, misPdf, p2, dv)) { shadow = true; sval = T * dv; sx = sd.x; }
                     if (pp.depth < pp.st.max_bounces) {
