@@ -314,9 +314,10 @@ class Core:
         self._check(self.lib.rtx_update_tile_samples(self.ctx))
 
     # ray queries (host arrays)
-    def trace_closest(self, rays: np.ndarray) -> np.ndarray:
+    def trace_closest(self, rays: np.ndarray, out: np.ndarray | None = None) -> np.ndarray:
         rays = np.ascontiguousarray(rays, RAY_DTYPE)
-        hits = np.empty(rays.shape[0], HIT_DTYPE)
+        hits = out if out is not None else np.empty(rays.shape[0], HIT_DTYPE)     # (a fresh array costs its page faults: reuse `out` in a loop)
+        assert hits.dtype == HIT_DTYPE and hits.shape[0] == rays.shape[0] and hits.flags.c_contiguous
         self._check(self.lib.rtx_trace_closest(self.ctx, rays.ctypes.data, rays.shape[0], hits.ctypes.data))
         return hits
 

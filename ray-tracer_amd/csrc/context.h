@@ -73,6 +73,7 @@ struct rtx_ctx {
     void* na_scratch = nullptr;    // this device's copy of the static scratch of the no-allocation entry point
     rtx::DevBuf b_io_a, b_io_b;    // staging for the host-pointer entry points
     rtx::PinBuf pin_in, pin_out;
+    hipEvent_t io_kernel_done[2] = {nullptr, nullptr};   // host-buffer ray queries: the kernel of a chunk has finished
     rtx::DevBuf b_counters;
 
     // progressive state

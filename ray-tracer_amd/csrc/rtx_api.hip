@@ -1,6 +1,10 @@
 // rtx_api.hip — implementation of the C ABI declared in include/rtx.h.
 #include <hip/hip_runtime.h>
 
+#include <functional>
+#include <thread>
+#include <condition_variable>
+
 #include <algorithm>
 #include <cfloat>
 #include <cstdarg>
@@ -167,6 +171,7 @@ void rtx_destroy(rtx_ctx* c)
         if (c->ev_shade[i]) (void)hipEventDestroy(c->ev_shade[i]);
         if (c->ev_shadow[i]) (void)hipEventDestroy(c->ev_shadow[i]);
     }
+    for (auto& e : c->io_kernel_done) if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_tiles) (void)hipEventDestroy(c->ev_tiles);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -491,42 +496,100 @@ int rtx_trace_closest_device_noalloc(rtx_ctx* c, const rtx_ray* rays, size_t n, 
     return RTX_OK;
 }
 
-// Host buffer -> device buffer through the pinned slots: the host threads fill one slot while the DMA engine drains
-// the other (a plain hipMemcpy from pageable memory moves ~10 GB/s).
-static int stage_in(rtx_ctx* c, const void* host, size_t bytes, void* dev)
-{
-    HIP_TRY(c->pin_in.ensure());
-    size_t k = 0;
-    for (size_t off = 0; off < bytes; off += PinBuf::kSlot, k++) {
-        const size_t len = std::min(PinBuf::kSlot, bytes - off);
-        char* slot = c->pin_in.p + (k & 1) * PinBuf::kSlot;
-        if (k >= 2) HIP_TRY(hipEventSynchronize(c->pin_in.ev[k & 1]));      // the DMA that last read this slot is done
-        parallel_ranges(len, [&](uint64_t a, uint64_t b) { std::memcpy(slot + a, (const char*)host + off + a, b - a); });
-        HIP_TRY(hipMemcpyAsync((char*)dev + off, slot, len, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipEventRecord(c->pin_in.ev[k & 1], c->stream));
+// Host-side copies between the caller's buffers and the pinned slots run on threads that stay around: starting sixteen
+// threads per 8 MB slot (what parallel_ranges does, fine for a scene upload) cost more than the copy itself.
+namespace {
+struct CopyPool {
+    std::mutex callers, m;
+    std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> workers;
+    const std::function<void(uint64_t, uint64_t)>* fn = nullptr;
+    uint64_t n = 0, per = 0, generation = 0;
+    int pending = 0;
+    explicit CopyPool(int threads)
+    {
+        for (int id = 0; id < threads; id++) workers.emplace_back([this, id]() {
+            uint64_t seen = 0;
+            std::unique_lock<std::mutex> lk(m);
+            for (;;) {
+                cv_work.wait(lk, [&] { return generation != seen; });
+                seen = generation;
+                const uint64_t b = (uint64_t)id * per, e = std::min(n, b + per);
+                const auto* f = fn;
+                lk.unlock();
+                if (b < e) (*f)(b, e);
+                lk.lock();
+                if (--pending == 0) cv_done.notify_one();
+            }
+        });
+        for (auto& t : workers) t.detach();
     }
-    return RTX_OK;
-}
-
-// Device buffer -> host buffer, the same way round; returns when `host` is complete.
-static int stage_out(rtx_ctx* c, const void* dev, size_t bytes, void* host)
+    void run(uint64_t count, const std::function<void(uint64_t, uint64_t)>& f)
+    {
+        if (count < (1u << 20)) { f(0, count); return; }
+        std::lock_guard<std::mutex> one_caller(callers);
+        std::unique_lock<std::mutex> lk(m);
+        const uint64_t parts = workers.size();
+        fn = &f; n = count; per = ((count + parts - 1) / parts + 4095) & ~(uint64_t)4095; pending = (int)parts; generation++;
+        cv_work.notify_all();
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+};
+CopyPool& copy_pool()
 {
+    // never destroyed: its threads wait on it until the process ends
+    static CopyPool* pool = new CopyPool((int)std::min(16u, std::max(2u, std::thread::hardware_concurrency())));
+    return *pool;
+}
+} // namespace
+
+// Ray queries on host buffers, in chunks of one pinned slot: while the host threads copy chunk k into its slot, the DMA
+// engines move chunk k - 1 in and the results of chunk k - 2 out (a stream each way, the kernels on the context's stream
+// between them), so that the call costs about what the host-side copies cost instead of copies + transfers + kernel
+// one after the other (a plain hipMemcpy from pageable memory moves ~10 GB/s). `launch` starts the query of `count`
+// items at device addresses `in` / `out` on c->stream. Returns when `host_out` is complete.
+static int staged_query(rtx_ctx* c, const void* host_in, size_t in_size, void* host_out, size_t out_size, size_t n,
+                        const std::function<int(void*, size_t, void*)>& launch)
+{
+    HIP_TRY(c->b_io_a.ensure(n * in_size));
+    HIP_TRY(c->b_io_b.ensure(n * out_size));
+    HIP_TRY(c->pin_in.ensure());
     HIP_TRY(c->pin_out.ensure());
-    const size_t n_slots = (bytes + PinBuf::kSlot - 1) / PinBuf::kSlot;
-    auto issue = [&](size_t k) -> hipError_t {
-        const size_t off = k * PinBuf::kSlot, len = std::min(PinBuf::kSlot, bytes - off);
-        hipError_t e = hipMemcpyAsync(c->pin_out.p + (k & 1) * PinBuf::kSlot, (const char*)dev + off, len, hipMemcpyDeviceToHost, c->stream);
-        return e == hipSuccess ? hipEventRecord(c->pin_out.ev[k & 1], c->stream) : e;
-    };
-    for (size_t k = 0; k < std::min<size_t>(2, n_slots); k++) HIP_TRY(issue(k));
-    for (size_t k = 0; k < n_slots; k++) {
-        const size_t off = k * PinBuf::kSlot, len = std::min(PinBuf::kSlot, bytes - off);
+    for (auto& e : c->io_kernel_done) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipStream_t s_in = c->pipe_stream[1], s_out = c->pipe_stream[2];
+    const size_t per = (PinBuf::kSlot / std::max(in_size, out_size)) & ~(size_t)63;
+    const size_t n_chunks = (n + per - 1) / per;
+    auto count_of = [&](size_t k) { return std::min(per, n - k * per); };
+    auto drain = [&](size_t k) -> int {          // results of chunk k: pinned slot -> caller's buffer
+        const size_t len = count_of(k) * out_size;
         const char* slot = c->pin_out.p + (k & 1) * PinBuf::kSlot;
         HIP_TRY(hipEventSynchronize(c->pin_out.ev[k & 1]));
-        parallel_ranges(len, [&](uint64_t a, uint64_t b) { std::memcpy((char*)host + off + a, slot + a, b - a); });
-        if (k + 2 < n_slots) HIP_TRY(issue(k + 2));
-    }
-    return RTX_OK;
+        copy_pool().run(len, [&](uint64_t a, uint64_t b) { std::memcpy((char*)host_out + k * per * out_size + a, slot + a, b - a); });
+        return RTX_OK;
+    };
+    auto body = [&]() -> int {
+        for (size_t k = 0; k < n_chunks; k++) {
+            const size_t cnt = count_of(k), p = k & 1;
+            char* slot = c->pin_in.p + p * PinBuf::kSlot;
+            if (k >= 2) HIP_TRY(hipEventSynchronize(c->pin_in.ev[p]));        // the transfer that last read this slot is done
+            copy_pool().run(cnt * in_size, [&](uint64_t a, uint64_t b) { std::memcpy(slot + a, (const char*)host_in + k * per * in_size + a, b - a); });
+            char* din = (char*)c->b_io_a.p + k * per * in_size; char* dout = (char*)c->b_io_b.p + k * per * out_size;
+            HIP_TRY(hipMemcpyAsync(din, slot, cnt * in_size, hipMemcpyHostToDevice, s_in));
+            HIP_TRY(hipEventRecord(c->pin_in.ev[p], s_in));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->pin_in.ev[p], 0));
+            int rc = launch(din, cnt, dout); if (rc) return rc;
+            HIP_TRY(hipEventRecord(c->io_kernel_done[p], c->stream));
+            // (the pinned output slot of this parity was emptied by drain(k - 2), one trip ago)
+            HIP_TRY(hipStreamWaitEvent(s_out, c->io_kernel_done[p], 0));
+            HIP_TRY(hipMemcpyAsync(c->pin_out.p + p * PinBuf::kSlot, dout, cnt * out_size, hipMemcpyDeviceToHost, s_out));
+            HIP_TRY(hipEventRecord(c->pin_out.ev[p], s_out));
+            if (k >= 1) { rc = drain(k - 1); if (rc) return rc; }
+        }
+        return drain(n_chunks - 1);
+    };
+    const int rc = body();
+    if (rc) { (void)hipStreamSynchronize(s_in); (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(s_out); }   // nothing may touch the pinned slots after the call
+    return rc;
 }
 
 int rtx_trace_closest(rtx_ctx* c, const rtx_ray* rays, size_t n, rtx_hit* hits)
@@ -536,14 +599,8 @@ int rtx_trace_closest(rtx_ctx* c, const rtx_ray* rays, size_t n, rtx_hit* hits)
     if (!rays || !hits) return fail(RTX_ERR_INVALID, "null buffer");
     if (!c->have_scene) return fail(RTX_ERR_STATE, "no scene uploaded");
     if (n > 0xF0000000ull) return fail(RTX_ERR_INVALID, "too many rays in one call");
-    HIP_TRY(c->b_io_a.ensure(n * sizeof(rtx_ray)));
-    HIP_TRY(c->b_io_b.ensure(n * sizeof(rtx_hit)));
-    int rc = stage_in(c, rays, n * sizeof(rtx_ray), c->b_io_a.p);
-    if (!rc) rc = rtx_trace_closest_device(c, c->b_io_a.as<rtx_ray>(), n, c->b_io_b.as<rtx_hit>());
-    if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }     // no DMA may still read the pinned slots after the call
-    rc = stage_out(c, c->b_io_b.p, n * sizeof(rtx_hit), hits);
-    if (rc) (void)hipStreamSynchronize(c->stream);
-    return rc;
+    return staged_query(c, rays, sizeof(rtx_ray), hits, sizeof(rtx_hit), n,
+                        [&](void* in, size_t count, void* out) { return rtx_trace_closest_device(c, (const rtx_ray*)in, count, (rtx_hit*)out); });
 }
 
 int rtx_trace_visible_device(rtx_ctx* c, const float* p1p2, size_t n, uint8_t* vis)
@@ -575,14 +632,8 @@ int rtx_trace_visible(rtx_ctx* c, const float* p1p2, size_t n, uint8_t* vis)
     if (!p1p2 || !vis) return fail(RTX_ERR_INVALID, "null buffer");
     if (!c->have_scene) return fail(RTX_ERR_STATE, "no scene uploaded");
     if (n > 0xF0000000ull) return fail(RTX_ERR_INVALID, "too many segments in one call");
-    HIP_TRY(c->b_io_a.ensure(n * 6 * sizeof(float)));
-    HIP_TRY(c->b_io_b.ensure(n));
-    int rc = stage_in(c, p1p2, n * 6 * sizeof(float), c->b_io_a.p);
-    if (!rc) rc = rtx_trace_visible_device(c, c->b_io_a.as<float>(), n, c->b_io_b.as<uint8_t>());
-    if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
-    rc = stage_out(c, c->b_io_b.p, n, vis);
-    if (rc) (void)hipStreamSynchronize(c->stream);
-    return rc;
+    return staged_query(c, p1p2, 6 * sizeof(float), vis, 1, n,
+                        [&](void* in, size_t count, void* out) { return rtx_trace_visible_device(c, (const float*)in, count, (uint8_t*)out); });
 }
 
 int rtx_generate_primary_rays_device(rtx_ctx* c, rtx_ray* rays, uint32_t* pixel, size_t cap)

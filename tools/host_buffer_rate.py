@@ -17,4 +17,10 @@ core.trace_closest(rays)
 t0 = time.perf_counter()
 for _ in range(5): h = core.trace_closest(rays)
 dt = (time.perf_counter() - t0) / 5
-print("host buffers in and out: %.2f ms per call, %.0f Mrays/s" % (dt * 1e3, n / dt / 1e6))
+print("host buffers in and out, a fresh output array per call: %.2f ms per call, %.0f Mrays/s" % (dt * 1e3, n / dt / 1e6))
+out = np.empty(n, pkg.HIT_DTYPE); core.trace_closest(rays, out)
+t0 = time.perf_counter()
+for _ in range(10): core.trace_closest(rays, out)
+dt = (time.perf_counter() - t0) / 10
+print("host buffers in and out, output array reused:          %.2f ms per call, %.0f Mrays/s" % (dt * 1e3, n / dt / 1e6))
+assert np.array_equal(out, h)
