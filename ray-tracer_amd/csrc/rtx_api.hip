@@ -93,6 +93,53 @@ int ensure_spill(rtx_ctx* c)
 
 } // namespace
 
+// Host-side copies between the caller's buffers and the pinned slots run on threads that stay around: starting sixteen
+// threads per 8 MB slot (what parallel_ranges does, fine for a scene upload) cost more than the copy itself.
+namespace {
+struct CopyPool {
+    std::mutex callers, m;
+    std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> workers;
+    const std::function<void(uint64_t, uint64_t)>* fn = nullptr;
+    uint64_t n = 0, per = 0, generation = 0;
+    int pending = 0;
+    explicit CopyPool(int threads)
+    {
+        for (int id = 0; id < threads; id++) workers.emplace_back([this, id]() {
+            uint64_t seen = 0;
+            std::unique_lock<std::mutex> lk(m);
+            for (;;) {
+                cv_work.wait(lk, [&] { return generation != seen; });
+                seen = generation;
+                const uint64_t b = (uint64_t)id * per, e = std::min(n, b + per);
+                const auto* f = fn;
+                lk.unlock();
+                if (b < e) (*f)(b, e);
+                lk.lock();
+                if (--pending == 0) cv_done.notify_one();
+            }
+        });
+        for (auto& t : workers) t.detach();
+    }
+    void run(uint64_t count, const std::function<void(uint64_t, uint64_t)>& f)
+    {
+        if (count < (1u << 20)) { f(0, count); return; }
+        std::lock_guard<std::mutex> one_caller(callers);
+        std::unique_lock<std::mutex> lk(m);
+        const uint64_t parts = workers.size();
+        fn = &f; n = count; per = ((count + parts - 1) / parts + 4095) & ~(uint64_t)4095; pending = (int)parts; generation++;
+        cv_work.notify_all();
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+};
+CopyPool& copy_pool()
+{
+    // never destroyed: its threads wait on it until the process ends
+    static CopyPool* pool = new CopyPool((int)std::min(16u, std::max(2u, std::thread::hardware_concurrency())));
+    return *pool;
+}
+} // namespace
+
 extern "C" {
 
 const char* rtx_last_error(void) { return g_err; }
@@ -497,53 +544,6 @@ int rtx_trace_closest_device_noalloc(rtx_ctx* c, const rtx_ray* rays, size_t n, 
     c->stats.closest_rays += n;
     return RTX_OK;
 }
-
-// Host-side copies between the caller's buffers and the pinned slots run on threads that stay around: starting sixteen
-// threads per 8 MB slot (what parallel_ranges does, fine for a scene upload) cost more than the copy itself.
-namespace {
-struct CopyPool {
-    std::mutex callers, m;
-    std::condition_variable cv_work, cv_done;
-    std::vector<std::thread> workers;
-    const std::function<void(uint64_t, uint64_t)>* fn = nullptr;
-    uint64_t n = 0, per = 0, generation = 0;
-    int pending = 0;
-    explicit CopyPool(int threads)
-    {
-        for (int id = 0; id < threads; id++) workers.emplace_back([this, id]() {
-            uint64_t seen = 0;
-            std::unique_lock<std::mutex> lk(m);
-            for (;;) {
-                cv_work.wait(lk, [&] { return generation != seen; });
-                seen = generation;
-                const uint64_t b = (uint64_t)id * per, e = std::min(n, b + per);
-                const auto* f = fn;
-                lk.unlock();
-                if (b < e) (*f)(b, e);
-                lk.lock();
-                if (--pending == 0) cv_done.notify_one();
-            }
-        });
-        for (auto& t : workers) t.detach();
-    }
-    void run(uint64_t count, const std::function<void(uint64_t, uint64_t)>& f)
-    {
-        if (count < (1u << 20)) { f(0, count); return; }
-        std::lock_guard<std::mutex> one_caller(callers);
-        std::unique_lock<std::mutex> lk(m);
-        const uint64_t parts = workers.size();
-        fn = &f; n = count; per = ((count + parts - 1) / parts + 4095) & ~(uint64_t)4095; pending = (int)parts; generation++;
-        cv_work.notify_all();
-        cv_done.wait(lk, [&] { return pending == 0; });
-    }
-};
-CopyPool& copy_pool()
-{
-    // never destroyed: its threads wait on it until the process ends
-    static CopyPool* pool = new CopyPool((int)std::min(16u, std::max(2u, std::thread::hardware_concurrency())));
-    return *pool;
-}
-} // namespace
 
 // Ray queries on host buffers, in chunks of one pinned slot: while the host threads copy chunk k into its slot, the DMA
 // engines move chunk k - 1 in and the results of chunk k - 2 out (a stream each way, the kernels on the context's stream
