@@ -705,12 +705,19 @@ __global__ __launch_bounds__(kBlock) void k_vpl_shade(WfPtrs w, DeviceScene sc, 
     }
 }
 
-__global__ void k_vpl_count(WfPtrs w)
+// number of VPLs the walk left (vpls.size() in RayTracer::radiosityLightPass, RTBase/Renderer.h:262-278): one workgroup
+__global__ __launch_bounds__(1024) void k_vpl_count(WfPtrs w)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        uint32_t c = 0;
-        for (uint32_t i = 0; i < w.vpl_slots; i++) c += w.vpl[10 * (size_t)i + 9] != 0.0f ? 1u : 0u;
-        *w.vpl_total = c;
+    __shared__ uint32_t s_part[1024 / 64];
+    uint32_t c = 0;
+    for (uint32_t i = threadIdx.x; i < w.vpl_slots; i += 1024u) c += w.vpl[10 * (size_t)i + 9] != 0.0f ? 1u : 0u;
+    for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o, 64);
+    if ((threadIdx.x & 63u) == 0) s_part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int i = 0; i < 1024 / 64; i++) total += s_part[i];
+        *w.vpl_total = total;
     }
 }
 
@@ -987,7 +994,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
                 std::swap(qin, qout);
             }
         }
-        hipLaunchKernelGGL(k_vpl_count, dim3(1), dim3(64), 0, s, w);
+        hipLaunchKernelGGL(k_vpl_count, dim3(1), dim3(1024), 0, s, w);
         // per-pixel gather, RTBase/Renderer.h:730-745
         pp.depth = 0;
         if (hipMemsetAsync(w.cnt, 0, kCounterWords * 4, s) != hipSuccess) return RTX_ERR_HIP;
