@@ -316,9 +316,10 @@ int rtx_count_closest_work(rtx_ctx* ctx, const rtx_ray* rays_dev, size_t n,
 /* The same for the renderer: n_passes passes exactly like rtx_render_passes renders them (the film advances, results
  * are identical), one at a time, with the traversal kernels instrumented. out[0] = closest-hit rays (live paths
  * summed over depths), out[1] = shadow / camera-connection segments, out[2] = wide nodes visited and out[3] = triangles
- * tested by all of them, out[4] = pixel samples (light paths) started, out[5] = leaf fetches. The visibility walks
- * inside the instant-radiosity gather (pixels x VPLs) are not counted. */
-int rtx_count_render_work(rtx_ctx* ctx, int n_passes, uint64_t out[6]);
+ * tested by all of them, out[4] = pixel samples (light paths) started, out[5] = leaf fetches. Instant radiosity:
+ * out[6] = the pixel-to-VPL segments the gather walked (those with a positive geometry term, RTBase/Renderer.h:229-240;
+ * they are part of out[1] too), out[7] = valid VPLs summed over the passes (vpls.size(), RTBase/Renderer.h:244). */
+int rtx_count_render_work(rtx_ctx* ctx, int n_passes, uint64_t out[8]);
 
 #ifdef __cplusplus
 }

@@ -355,9 +355,9 @@ class Core:
 
     def count_render_work(self, n_passes: int = 1) -> dict:
         """n instrumented passes (the film advances as usual): rays, nodes visited, triangles tested."""
-        out = (C.c_uint64 * 6)()
+        out = (C.c_uint64 * 8)()
         self._check(self.lib.rtx_count_render_work(self.ctx, n_passes, out))
-        return dict(zip(("closest_rays", "shadow_rays", "nodes", "tris", "samples", "tri_groups"), (int(v) for v in out)))
+        return dict(zip(("closest_rays", "shadow_rays", "nodes", "tris", "samples", "tri_groups", "gather_segments", "vpls"), (int(v) for v in out)))
 
     # introspection
     def bvh(self):

@@ -13,7 +13,7 @@ namespace rtx {
 
 constexpr int kBlock = 256;        // threads per workgroup (4 waves)
 constexpr int kLdsStack = 12;      // traversal-stack entries per lane kept in LDS
-constexpr int kMinLdsStack = 4;    // smallest LDS part of any kernel variant (sizes the global spill slab)
+constexpr int kMinLdsStack = 0;    // smallest LDS part of any kernel (sizes the global spill slab): the exact path of the packet kernels keeps its whole stack in global memory
 constexpr int kMaxGridBlocks = 2048;   // 256 CUs x 8 resident workgroups
 constexpr int kPipeline = 4;       // render passes in flight at most (one stream and one set of path state each)
 
@@ -55,6 +55,8 @@ struct rtx_ctx {
     int device = 0;
     int variant = 1;               // traversal schedule (RTX_VARIANT): 1 = default, 0 = static baseline, >= 2 = schedules under test
     int resident_blocks = rtx::kMaxGridBlocks;   // traversal workgroups the device holds at once
+    int resident_packet_blocks = rtx::kMaxGridBlocks;   // the same for the packet kernels (traverse_packet.h)
+    int ir_packet = 1;             // instant-radiosity gather: one traversal per wave (RTX_IR_PACKET=0: one per lane)
     int rays_per_block = 16;       // grid of a ray-query launch too small to fill the device: one workgroup per this many rays
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

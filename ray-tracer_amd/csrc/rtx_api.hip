@@ -175,6 +175,9 @@ static int create_resources(rtx_ctx* c, int device)
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_closest<false>, kBlock, 0));
         c->resident_blocks = std::max(1, std::min(kMaxGridBlocks, per_cu * prop.multiProcessorCount));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_ir_trace_packet, kBlock, 0));
+        c->resident_packet_blocks = std::max(1, std::min(kMaxGridBlocks, per_cu * prop.multiProcessorCount));
+        if (const char* v = getenv("RTX_IR_PACKET")) c->ir_packet = atoi(v);
         if (const char* g = getenv("RTX_GRID")) c->resident_blocks = std::max(1, std::min(kMaxGridBlocks, atoi(g)));   // tuning override
         if (getenv("RTX_DEBUG_COUNTERS")) fprintf(stderr, "[rtx] %d CUs x %d resident traversal workgroups\n", prop.multiProcessorCount, per_cu);
     }
@@ -710,7 +713,7 @@ int rtx_count_closest_work(rtx_ctx* c, const rtx_ray* rays, size_t n, uint64_t* 
     return RTX_OK;
 }
 
-int rtx_count_render_work(rtx_ctx* c, int n_passes, uint64_t out[6])
+int rtx_count_render_work(rtx_ctx* c, int n_passes, uint64_t out[8])
 {
     CTX_TRY(c);
     if (!c->have_scene || !c->have_camera) return fail(RTX_ERR_STATE, "scene and camera must be set before rendering");
@@ -718,23 +721,28 @@ int rtx_count_render_work(rtx_ctx* c, int n_passes, uint64_t out[6])
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemsetAsync(c->b_counters.p, 0, 4 * kWorkSlotWords, c->stream));
     if (c->spill_lanes < 2) { c->spill_lanes = 2; int rc = ensure_spill(c); if (rc) return rc; }
-    for (int i = 0; i < 6; i++) out[i] = 0;
+    for (int i = 0; i < 8; i++) out[i] = 0;
     std::vector<uint32_t> q(2 * 96 * kQueueStride);
+    const bool radiosity = c->settings.algorithm == RTX_AL_INSTANT_RADIOSITY && c->settings.draw_mode == RTX_DM_ALGORITHM;
     c->count_work = true; c->passes_in_flight = 1;
     for (int i = 0; i < n_passes; i++) {
         const uint64_t before = c->stats.samples;
         int rc = wavefront_render_pass(c, 0, c->stream, nullptr, nullptr, false);
         hipError_t e = rc ? hipSuccess : hipMemcpyAsync(q.data(), c->wf[0]->p.cnt, q.size() * 4, hipMemcpyDeviceToHost, c->stream);
+        uint32_t vpls = 0;
+        if (!rc && e == hipSuccess && radiosity) e = hipMemcpyAsync(&vpls, c->wf[0]->p.vpl_total, 4, hipMemcpyDeviceToHost, c->stream);
         if (!rc && e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (rc || e != hipSuccess) { c->count_work = false; return fail(rc ? rc : RTX_ERR_HIP, "instrumented render pass failed: %s", hipGetErrorString(e)); }
         // queue lengths of the pass: live paths per depth (one closest-hit ray each), shadow / connection segments per depth
-        for (int d = 0; d < 96; d++) { out[0] += q[d * kQueueStride]; out[1] += q[(96 + d) * kQueueStride]; }
-        out[4] += c->stats.samples - before;
+        // (instant radiosity: the counters are cleared between the VPL walk and the gather, so its light paths' few rays
+        // are not in the sums; queue 1 of the gather holds the gathering pixels, which are no rays)
+        for (int d = 0; d < 96; d++) { if (!(radiosity && d == 1)) out[0] += q[d * kQueueStride]; out[1] += q[(96 + d) * kQueueStride]; }
+        out[4] += c->stats.samples - before; out[7] += vpls;
     }
     c->count_work = false;
-    unsigned long long h[6];
+    unsigned long long h[8];
     HIP_TRY(hipMemcpy(h, c->b_counters.p, sizeof h, hipMemcpyDeviceToHost));
-    out[2] = h[0]; out[3] = h[1]; out[5] = h[5];
+    out[2] = h[0]; out[3] = h[1]; out[5] = h[5]; out[6] = h[6]; out[1] += h[6];
     return RTX_OK;
 }
 

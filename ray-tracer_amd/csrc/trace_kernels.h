@@ -65,10 +65,11 @@ __global__ __launch_bounds__(kBlock) void k_closest_static(DeviceScene sc, const
 struct ClosestPolicy {
     const DeviceScene& sc; const rtx_ray* rays; const uint32_t* queue; rtx_hit* hits;
     __device__ __forceinline__ uint32_t index(uint32_t k) const { return queue ? queue[k] : k; }
-    __device__ __forceinline__ void fetch(uint32_t k, float o[3], float d[3], float& maxT) const
+    __device__ __forceinline__ bool fetch(uint32_t k, float o[3], float d[3], float& maxT) const
     {
         const rtx_ray r = rays[index(k)];
         o[0] = r.o[0]; o[1] = r.o[1]; o[2] = r.o[2]; d[0] = r.d[0]; d[1] = r.d[1]; d[2] = r.d[2]; maxT = 0.0f;
+        return true;
     }
     __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool) const { hits[index(k)] = make_hit(sc, best); }
     // instrumented runs only: the ray's node visits and triangle tests replace two barycentrics of the (scratch) hit record
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, W
 // A segment whose ray misses the root box is NOT visible (Geometry.h:571-572).
 struct VisiblePolicy {
     const float* segments; uint8_t* visible;
-    __device__ __forceinline__ void fetch(uint32_t k, float o[3], float d[3], float& maxT) const { segment_to_ray(segments + (size_t)k * 6, o, d, maxT); }
+    __device__ __forceinline__ bool fetch(uint32_t k, float o[3], float d[3], float& maxT) const { segment_to_ray(segments + (size_t)k * 6, o, d, maxT); return true; }
     __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool reached) const { visible[k] = (reached && best.pos == 0xFFFFFFFFu) ? 1 : 0; }
 };
 

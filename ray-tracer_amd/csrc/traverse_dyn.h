@@ -14,7 +14,8 @@
 // the order of independent steps differ.
 //
 // A Policy supplies the items and consumes the results:
-//   void  fetch(uint32_t k, float o[3], float d[3], float& maxT)   load item k (k < n)
+//   bool  fetch(uint32_t k, float o[3], float d[3], float& maxT)   load item k (k < n); false: the item needs no walk and is done
+//                                                                   (the policy has recorded its result itself)
 //   void  retire(uint32_t k, const HitRec& best, bool reached)     reached == false: the ray missed the root box
 // MODE selects what a ray asks for: kModeClosest (closest hit), kModeAny (visibility: any hit with t <= maxT ends
 // the ray) or kModeMixed, where every item says which of the two it is (fetch takes a further `bool& any`): one
@@ -219,14 +220,16 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
                 const uint32_t x = loc_next + rank;
                 const uint32_t k = fine ? n_coarse + ((((x >> GL) * (uint32_t)kWorkSegments + seg) << GL) | (x & GM)) : x;
                 float o[3], d[3];
-                if constexpr (MODE == kModeMixed) pol.fetch(k, o, d, maxT, any_lane); else pol.fetch(k, o, d, maxT);
+                bool walk;
+                if constexpr (MODE == kModeMixed) walk = pol.fetch(k, o, d, maxT, any_lane); else walk = pol.fetch(k, o, d, maxT);
                 ox = o[0]; oy = o[1]; oz = o[2]; dx = d[0]; dy = d[1]; dz = d[2];
                 ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;                                    // Ray::init, Geometry.h:25
                 best.t = FLT_MAX; best.u = best.v = 0; best.pos = kNone; stk.sp = 0;
                 if constexpr (SHARE != 0) { if (tail) { ts->key[threadIdx.x] = pack_hit(best); ts->pending[threadIdx.x] = 0u; } }   // a fresh mailbox for the new ray
                 bound = RTX_IS_ANY ? (maxT + (fabsf(maxT) * kCullRel + kCullAbs)) : FLT_MAX;
                 // root box first (Geometry.h:509 / :571)
-                if (slab_reference(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ox, oy, oz, ix, iy, iz)) {
+                if (!walk) {}
+                else if (slab_reference(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ox, oy, oz, ix, iy, iz)) {
                     const bool finite = (fabsf(ix) <= FLT_MAX) && (fabsf(iy) <= FLT_MAX) && (fabsf(iz) <= FLT_MAX);
                     if (finite) {
                         cur = 0; item = k; mark = cnt;

@@ -16,6 +16,7 @@
 #include "context.h"
 #include "shade.h"
 #include "trace_kernels.h"
+#include "traverse_packet.h"
 
 namespace rtx {
 
@@ -44,7 +45,8 @@ struct WfPtrs {
     float* sval;       // [P][3] contribution carried by the shadow ray
     float* sxy;        // [P][2] splat position (light tracing)
     uint32_t* spath;   // [P]    path slot the contribution belongs to
-    float* vpl;        // [V][10] x(3) n(3) Le(3) valid
+    float* vpl;        // [V][10] x(3) n(3) Le(3) valid, slot j * (maxBounces + 1) + d of light path j
+    float* vplc;       // [<= V][10] the valid ones, packed in list order
     uint32_t* vpl_total;
     float* film; uint32_t* tile_samples;
     uint32_t* tile_off;   // [n_tiles] queue offset of the tile's first camera sample this pass
@@ -52,7 +54,7 @@ struct WfPtrs {
 };
 
 struct WavefrontBuffers {
-    DevBuf ray, hit, T, L, xy, key, dim, mis, flags, qa, qb, cnt, sseg, sval, sxy, spath, vpl, vpl_total, tile_off;
+    DevBuf ray, hit, T, L, xy, key, dim, mis, flags, qa, qb, cnt, sseg, sval, sxy, spath, vpl, vpl_total, tile_off, ir_vis;
     WfPtrs p{};
     uint32_t vpl_capacity = 0;
 };
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(kBlock) void k_pt_shade(WfPtrs w, DeviceScene sc, P
 // (Renderer.h:448-452, 463-469).
 struct ShadowAccumulatePolicy {
     const WfPtrs& w;
-    __device__ __forceinline__ void fetch(uint32_t k, float o[3], float d[3], float& maxT) const { segment_to_ray(w.sseg + 6 * (size_t)k, o, d, maxT); }
+    __device__ __forceinline__ bool fetch(uint32_t k, float o[3], float d[3], float& maxT) const { segment_to_ray(w.sseg + 6 * (size_t)k, o, d, maxT); return true; }
     __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool reached) const
     {
         if (reached && best.pos == 0xFFFFFFFFu) {
@@ -362,12 +364,13 @@ __global__ __launch_bounds__(kBlock) void k_closest_counted(DeviceScene sc, cons
 // [0, n_closest) are the live paths of `queue`, items from n_closest on the shadow segments.
 struct PtMixedPolicy {
     const DeviceScene& sc; const WfPtrs& w; const uint32_t* queue; uint32_t n_closest;
-    __device__ __forceinline__ void fetch(uint32_t k, float o[3], float d[3], float& maxT, bool& any) const
+    __device__ __forceinline__ bool fetch(uint32_t k, float o[3], float d[3], float& maxT, bool& any) const
     {
         if (k < n_closest) {
             const rtx_ray r = w.ray[queue[k]];
             o[0] = r.o[0]; o[1] = r.o[1]; o[2] = r.o[2]; d[0] = r.d[0]; d[1] = r.d[1]; d[2] = r.d[2]; maxT = 0.0f; any = false;
         } else { segment_to_ray(w.sseg + 6 * (size_t)(k - n_closest), o, d, maxT); any = true; }
+        return true;
     }
     __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool reached) const
     {
@@ -587,7 +590,7 @@ __global__ __launch_bounds__(kBlock) void k_lt_shade(WfPtrs w, DeviceScene sc, C
 // Camera connections of one stage: visible ones splat onto the film (Renderer.h:325-331)
 struct SplatPolicy {
     const WfPtrs& w; int filter;
-    __device__ __forceinline__ void fetch(uint32_t k, float o[3], float d[3], float& maxT) const { segment_to_ray(w.sseg + 6 * (size_t)k, o, d, maxT); }
+    __device__ __forceinline__ bool fetch(uint32_t k, float o[3], float d[3], float& maxT) const { segment_to_ray(w.sseg + 6 * (size_t)k, o, d, maxT); return true; }
     __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool reached) const
     {
         if (reached && best.pos == 0xFFFFFFFFu)
@@ -607,12 +610,13 @@ __global__ __launch_bounds__(kBlock) void k_lt_splat(WfPtrs w, DeviceScene sc, u
 // path tracer's shadow rays): items [0, n_closest) are the live light paths of `queue`, the others connection segments.
 struct LtMixedPolicy {
     const DeviceScene& sc; const WfPtrs& w; const uint32_t* queue; uint32_t n_closest; int filter;
-    __device__ __forceinline__ void fetch(uint32_t k, float o[3], float d[3], float& maxT, bool& any) const
+    __device__ __forceinline__ bool fetch(uint32_t k, float o[3], float d[3], float& maxT, bool& any) const
     {
         if (k < n_closest) {
             const rtx_ray r = w.ray[queue[k]];
             o[0] = r.o[0]; o[1] = r.o[1]; o[2] = r.o[2]; d[0] = r.d[0]; d[1] = r.d[1]; d[2] = r.d[2]; maxT = 0.0f; any = false;
         } else { segment_to_ray(w.sseg + 6 * (size_t)(k - n_closest), o, d, maxT); any = true; }
+        return true;
     }
     __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool reached) const
     {
@@ -705,53 +709,203 @@ __global__ __launch_bounds__(kBlock) void k_vpl_shade(WfPtrs w, DeviceScene sc, 
     }
 }
 
-// number of VPLs the walk left (vpls.size() in RayTracer::radiosityLightPass, RTBase/Renderer.h:262-278): one workgroup
-__global__ __launch_bounds__(1024) void k_vpl_count(WfPtrs w)
+// The VPLs the walk left, in list order (vpls in RayTracer::radiosityLightPass, RTBase/Renderer.h:262-278: path by
+// path, along each path), packed into w.vplc; their number goes to *w.vpl_total. One workgroup.
+__global__ __launch_bounds__(1024) void k_vpl_compact(WfPtrs w)
 {
-    __shared__ uint32_t s_part[1024 / 64];
-    uint32_t c = 0;
-    for (uint32_t i = threadIdx.x; i < w.vpl_slots; i += 1024u) c += w.vpl[10 * (size_t)i + 9] != 0.0f ? 1u : 0u;
-    for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o, 64);
-    if ((threadIdx.x & 63u) == 0) s_part[threadIdx.x >> 6] = c;
+    __shared__ uint32_t s_wave[1024 / 64], s_base;
+    if (threadIdx.x == 0) s_base = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t total = 0;
-        for (int i = 0; i < 1024 / 64; i++) total += s_part[i];
-        *w.vpl_total = total;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t i0 = 0; i0 < w.vpl_slots; i0 += 1024u) {
+        const uint32_t i = i0 + threadIdx.x;
+        const bool valid = i < w.vpl_slots && w.vpl[10 * (size_t)i + 9] != 0.0f;
+        const unsigned long long mask = __ballot(valid);
+        if (lane == 0) s_wave[wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        if (valid) {
+            uint32_t at = s_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            for (uint32_t j = 0; j < wave; j++) at += s_wave[j];
+            for (int q = 0; q < 10; q++) w.vplc[10 * (size_t)at + q] = w.vpl[10 * (size_t)i + q];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t t = 0; for (int j = 0; j < 1024 / 64; j++) t += s_wave[j]; s_base += t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *w.vpl_total = s_base;
+}
+
+// RayTracer::radiosityLightPass + radiosityComputeDirect, RTBase/Renderer.h:210-278: every pixel gathers from every
+// VPL, in list order. Three kernels instead of one loop per pixel:
+//   k_ir_prepare  shading data of every primary hit; pixels that gather (a hit on a surface that is neither a light
+//                 nor purely specular) get a place g in the gather queue and a record of what BSDF::evaluate needs
+//   k_ir_trace    the pixels x VPLs visibility segments as items of the dynamic traversal; item k of a launch is
+//                 (VPL v0 + k / ng, pixel g = k % ng), so the rays in flight together leave neighbouring pixels for
+//                 the same VPL. An item whose geometry term is not positive is done at fetch, without a walk. Result:
+//                 one byte per item, 1 = the VPL contributes to the pixel
+//   k_ir_shade    per pixel, the contributions of the VPLs marked 1, summed in list order like the reference's loop
+// A launch covers the VPLs [v0, v0 + vb); the host runs as many launches as the upper bound of the VPL count needs.
+// The gather record of place g: x and shading normal in sseg[g], wo in T[g], albedo in sval[g], material in spath[g].
+__global__ __launch_bounds__(kBlock) void k_ir_prepare(WfPtrs w, DeviceScene sc, PassParams pp)
+{
+    const uint32_t n = w.cnt[(0) * kQueueStride];
+    const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+    for (uint32_t it = 0; it < rounds; it++) {
+        const uint32_t i = it * gridDim.x * kBlock + global_thread();
+        bool gather = false; uint32_t slot = 0; Shading sd; sd.mat = nullptr;
+        if (i < n) {
+            slot = w.qa[i];
+            const rtx_hit h = w.hit[slot]; const rtx_ray r = w.ray[slot];
+            C3 L = mkc(0, 0, 0);
+            if (h.t < FLT_MAX) {
+                shading_data(sc, h, ld3(r.o), ld3(r.d), sd);
+                if (isPureSpecular(*sd.mat)) L = mkc(0, 0, 0);
+                else if (sd.mat->is_light) L = pp.st.can_hit_light ? ldc(sd.mat->emission) : mkc(0, 0, 0);
+                else gather = true;
+            } else L = background_evaluate(sc, ld3(r.d));
+            if (!gather) st3(w.L + 3 * slot, L);
+        }
+        const uint32_t g = queue_slot(gather, &w.cnt[(1) * kQueueStride]);
+        if (gather) {
+            w.qb[g] = slot;
+            st3(w.sseg + 6 * (size_t)g, sd.x); st3(w.sseg + 6 * (size_t)g + 3, sd.sNormal);
+            st3(w.T + 3 * (size_t)g, sd.wo); st3(w.sval + 3 * (size_t)g, sd.alb);
+            w.spath[g] = (uint32_t)(sd.mat - sc.materials);
+        }
     }
 }
 
-// RayTracer::radiosityLightPass + radiosityComputeDirect, RTBase/Renderer.h:210-278: every
-// pixel gathers from every VPL, in list order
-__global__ __launch_bounds__(kBlock) void k_ir_gather(WfPtrs w, DeviceScene sc, PassParams pp, uint2* spill, uint32_t spill_stride)
+// geometry term between a gather point and a VPL, Renderer.h:229-236; wi comes back normalised
+__device__ __forceinline__ float ir_geometry(V3 x, V3 ns, V3 vx, V3 vn, V3& wi)
+{
+    wi = vx - x; const float lsq = lengthSq(wi); wi = normalize(wi);
+    return (wmax(dot(wi, ns), 0.0f) * wmax(-dot(wi, vn), 0.0f)) / lsq;
+}
+
+struct IrGatherPolicy {
+    const WfPtrs& w; uint32_t ng, v0; uint8_t* vis; unsigned long long* counters;
+    __device__ __forceinline__ bool fetch(uint32_t k, float o[3], float d[3], float& maxT) const
+    {
+        const uint32_t vl = k / ng, g = k - vl * ng;
+        const float* v = w.vplc + 10 * (size_t)(v0 + vl); const float* r = w.sseg + 6 * (size_t)g;
+        const V3 x = ld3(r), vx = ld3(v);
+        V3 wi;
+        if (!(ir_geometry(x, ld3(r + 3), vx, ld3(v + 3), wi) > 0)) {
+            vis[k] = 0; o[0] = o[1] = o[2] = 0.0f; d[0] = d[1] = d[2] = 0.0f; maxT = 0.0f;
+            return false;
+        }
+        const float s[6] = {x.x, x.y, x.z, vx.x, vx.y, vx.z};
+        segment_to_ray(s, o, d, maxT);
+        return true;
+    }
+    __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool reached) const { vis[k] = (reached && best.pos == 0xFFFFFFFFu) ? 1 : 0; }
+    // instrumented runs: one more segment walked
+    __device__ __forceinline__ void note(uint32_t, uint32_t, uint32_t) const { atomicAdd(&counters[6], 1ull); }
+};
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_ir_trace(WfPtrs w, DeviceScene sc, uint32_t v0, uint32_t vb, uint8_t* vis, uint32_t work_index, uint2* spill, uint32_t spill_stride,
+                                                     unsigned long long* counters)
 {
     __shared__ unsigned long long lds[kBlock * kLdsStack];
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
-    const uint32_t n = w.cnt[(0) * kQueueStride];
-    const uint32_t total = *w.vpl_total;
-    for (uint32_t i = global_thread(); i < n; i += gridDim.x * kBlock) {
-        const uint32_t slot = w.qa[i];
-        const rtx_hit h = w.hit[slot]; const rtx_ray r = w.ray[slot];
-        C3 L = mkc(0, 0, 0);
-        if (h.t < FLT_MAX) {
-            Shading sd; shading_data(sc, h, ld3(r.o), ld3(r.d), sd);
-            if (isPureSpecular(*sd.mat)) L = mkc(0, 0, 0);
-            else if (sd.mat->is_light) L = pp.st.can_hit_light ? ldc(sd.mat->emission) : mkc(0, 0, 0);
-            else {
-                C3 acc = mkc(0, 0, 0);
-                for (uint32_t k = 0; k < w.vpl_slots; k++) {
-                    const float* v = w.vpl + 10 * (size_t)k;
-                    if (v[9] == 0.0f) continue;
-                    V3 vx = ld3(v), vn = ld3(v + 3);
-                    V3 wi = vx - sd.x; float lsq = lengthSq(wi); wi = normalize(wi);
-                    float g = (wmax(dot(wi, sd.sNormal), 0.0f) * wmax(-dot(wi, vn), 0.0f)) / lsq;
-                    if (g > 0 && segment_visible(sc, stk, sd.x.x, sd.x.y, sd.x.z, vx.x, vx.y, vx.z))
-                        acc = acc + bsdf_evaluate(sc, sd, wi) * ldc(v + 6) * g;
+    const uint32_t ng = w.cnt[(1) * kQueueStride], total = *w.vpl_total;
+    const uint32_t nv = total > v0 ? min(vb, total - v0) : 0u;
+    IrGatherPolicy pol{w, ng, v0, vis, counters};
+    __shared__ TailShare<kBlock> ts;
+    traverse_dyn<IrGatherPolicy, kModeAny, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, COUNT ? 0 : kShare>(sc, stk, ng * nv, w.cnt + work_index, pol, counters, &ts);
+}
+
+// k_ir_trace as one traversal per wave (traverse_packet.h): consecutive items are neighbouring pixels gathering from the
+// same VPL, so their segments pass the same nodes. A wave draws super-chunks of 256 (pixel, VPL) pairs from 64
+// interleaved counters (as traverse_dyn does, so that the atomics do not queue on one address and the whole grid
+// sweeps the pairs on one front), evaluates the geometry term of 64 pairs at a time, marks the culled ones done and
+// collects the others in a small ring in LDS; whenever the ring holds a full wave of segments (or the pairs have
+// run out) it walks them as one packet. Same result bytes as k_ir_trace.
+__global__ __launch_bounds__(kBlock) void k_ir_trace_packet(WfPtrs w, DeviceScene sc, uint32_t v0, uint32_t vb, uint8_t* vis, uint32_t work_index, uint2* spill, uint32_t spill_stride)
+{
+    __shared__ PacketStacks<kBlock> ps;
+    __shared__ uint32_t s_ring[kBlock / 64][128];
+    LaneStack<kBlock, 0> exact_stack; exact_stack.init(nullptr, spill, spill_stride);
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t ng = w.cnt[(1) * kQueueStride], total = *w.vpl_total;
+    const uint32_t nv = total > v0 ? min(vb, total - v0) : 0u;
+    const uint32_t n = ng * nv, n_super = (n + 255u) / 256u;
+    uint32_t* work = w.cnt + work_index;
+    uint32_t seg = blockIdx.x % (uint32_t)kWorkSegments;
+    unsigned long long dry = 0ull;                  // counters this wave has found empty
+    bool exhausted = n == 0u;
+    uint32_t pair_next = 0, pair_end = 0, ring_head = 0, ring_count = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (;;) {
+        while (ring_count < 64u && !exhausted) {
+            if (pair_next == pair_end) {
+                uint32_t j = 0;
+                if (lane == 0) j = atomicAdd(work + seg * (uint32_t)kWorkStride, 1u);
+                j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+                const uint32_t g = work_chunk(j, seg);
+                if (j >= (1u << 24) || g >= n_super) {
+                    // all counters advance on one front: when this one is empty the others have at most a few chunks left
+                    dry |= 1ull << seg;
+                    if (dry == ~0ull) { exhausted = true; break; }
+                    do { seg = (seg + 1u) & (uint32_t)(kWorkSegments - 1); } while ((dry >> seg) & 1ull);
+                    continue;
                 }
-                L = acc / (float)total;
+                pair_next = g * 256u; pair_end = min(pair_next + 256u, n);
             }
-        } else L = background_evaluate(sc, ld3(r.d));
-        st3(w.L + 3 * slot, L);
+            const uint32_t k = pair_next + lane;
+            bool keep = false;
+            if (k < pair_end) {
+                const uint32_t vl = k / ng, g = k - vl * ng;
+                const float* v = w.vplc + 10 * (size_t)(v0 + vl); const float* r = w.sseg + 6 * (size_t)g;
+                V3 wi;
+                keep = ir_geometry(ld3(r), ld3(r + 3), ld3(v), ld3(v + 3), wi) > 0;
+                if (!keep) vis[k] = 0;
+            }
+            const unsigned long long km = __ballot(keep);
+            if (keep) s_ring[wv][(ring_head + ring_count + (uint32_t)__popcll(km & below)) & 127u] = k;
+            ring_count += (uint32_t)__popcll(km);
+            pair_next = min(pair_next + 64u, pair_end);
+        }
+        if (ring_count == 0u) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // the ring entries other lanes wrote
+        const uint32_t take = min(64u, ring_count);
+        const bool has = lane < take;
+        const uint32_t k = has ? s_ring[wv][(ring_head + lane) & 127u] : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        ring_head = (ring_head + take) & 127u; ring_count -= take;
+        float o[3] = {0, 0, 0}, d[3] = {1, 1, 1}, maxT = 0.0f;
+        if (has) {
+            const uint32_t vl = k / ng, g = k - vl * ng;
+            const float* v = w.vplc + 10 * (size_t)(v0 + vl); const float* r = w.sseg + 6 * (size_t)g;
+            const float s[6] = {r[0], r[1], r[2], v[0], v[1], v[2]};
+            segment_to_ray(s, o, d, maxT);
+        }
+        const bool blocked = packet_occluded<kBlock, false>(sc, ps, exact_stack, has, o[0], o[1], o[2], d[0], d[1], d[2], maxT, nullptr, nullptr);
+        if (has) vis[k] = blocked ? 0 : 1;
+    }
+}
+
+// first: the sum starts at zero (otherwise it carries on from the launch before); last: divide by vpls.size(), Renderer.h:244
+__global__ __launch_bounds__(kBlock) void k_ir_shade(WfPtrs w, DeviceScene sc, uint32_t v0, uint32_t vb, const uint8_t* __restrict__ vis, int first, int last)
+{
+    const uint32_t ng = w.cnt[(1) * kQueueStride], total = *w.vpl_total;
+    const uint32_t nv = total > v0 ? min(vb, total - v0) : 0u;
+    for (uint32_t g = global_thread(); g < ng; g += gridDim.x * kBlock) {
+        const uint32_t slot = w.qb[g];
+        Shading sd;
+        sd.x = ld3(w.sseg + 6 * (size_t)g); sd.sNormal = ld3(w.sseg + 6 * (size_t)g + 3); sd.wo = ld3(w.T + 3 * (size_t)g);
+        sd.alb = ldc(w.sval + 3 * (size_t)g); sd.mat = &sc.materials[w.spath[g]];
+        sd.gNormal = sd.sNormal; sd.tu = sd.tv = 0.0f; sd.t = 0.0f;
+        sd.frame.fromVector(sd.sNormal);
+        C3 acc = first ? mkc(0, 0, 0) : ldc(w.L + 3 * slot);
+        for (uint32_t vl = 0; vl < nv; vl++) {
+            if (!vis[(size_t)vl * ng + g]) continue;
+            const float* v = w.vplc + 10 * (size_t)(v0 + vl);
+            V3 wi; const float gt = ir_geometry(sd.x, sd.sNormal, ld3(v), ld3(v + 3), wi);
+            acc = acc + bsdf_evaluate(sc, sd, wi) * ldc(v + 6) * gt;
+        }
+        if (last) acc = acc / (float)total;
+        st3(w.L + 3 * slot, acc);
     }
 }
 
@@ -981,8 +1135,8 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         const uint32_t n_paths = st.vpl_rays_per_tile * st.num_threads;
         if (n_paths > w.P) return RTX_ERR_INVALID;
         const uint32_t slots = n_paths * (st.max_bounces + 1);
-        if (b.vpl.ensure(std::max<size_t>((size_t)slots * 40, 16)) != hipSuccess) return RTX_ERR_NOMEM;
-        w.vpl = b.vpl.as<float>(); w.vpl_slots = slots;
+        if (b.vpl.ensure(std::max<size_t>((size_t)slots * 80, 16)) != hipSuccess) return RTX_ERR_NOMEM;
+        w.vpl = b.vpl.as<float>(); w.vplc = w.vpl + 10 * (size_t)slots; w.vpl_slots = slots;
         if (slots && hipMemsetAsync(w.vpl, 0, (size_t)slots * 40, s) != hipSuccess) return RTX_ERR_HIP;
         if (n_paths) {
             hipLaunchKernelGGL(k_vpl_emit, dim3((n_paths + kBlock - 1) / kBlock), blk, 0, s, w, dscene, pp, n_paths);
@@ -994,14 +1148,34 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
                 std::swap(qin, qout);
             }
         }
-        hipLaunchKernelGGL(k_vpl_count, dim3(1), dim3(1024), 0, s, w);
-        // per-pixel gather, RTBase/Renderer.h:730-745
+        hipLaunchKernelGGL(k_vpl_compact, dim3(1), dim3(1024), 0, s, w);
+        // per-pixel gather, RTBase/Renderer.h:730-745. The device knows how many pixels gather and how many VPLs are
+        // valid; the host sizes the launches for the upper bounds (every pixel, every slot): vb VPLs per launch, so
+        // that a launch has fewer than 2^32 items and its result bytes fit the buffer.
+        uint32_t vb = slots, batches = slots ? 1u : 0u;
+        if (slots) {
+            const uint64_t cap = 1ull << 30;
+            vb = (uint32_t)std::max<uint64_t>(std::max<uint64_t>(cap / w.P, 1), (slots + 63u) / 64u);
+            vb = std::min(vb, slots); batches = (slots + vb - 1u) / vb;
+            if ((uint64_t)vb * w.P > 0xF0000000ull) return RTX_ERR_INVALID;      // (a film and a VPL count far beyond any use)
+            if (b.ir_vis.ensure((size_t)vb * w.P) != hipSuccess) return RTX_ERR_NOMEM;
+        }
         pp.depth = 0;
         if (hipMemsetAsync(w.cnt, 0, kCounterWords * 4, s) != hipSuccess) return RTX_ERR_HIP;
         hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, w, pp);
         hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
         closest(w.qa, 0);
-        hipLaunchKernelGGL(k_ir_gather, gridQ, blk, 0, s, w, dscene, pp, spill, sstride);
+        hipLaunchKernelGGL(k_ir_prepare, gridQ, blk, 0, s, w, dscene, pp);
+        for (uint32_t bi = 0; bi < std::max(batches, 1u); bi++) {
+            const uint32_t v0 = bi * vb, work = (uint32_t)(kShadowWorkBase + bi * kWorkSlotWords);
+            uint8_t* vis = b.ir_vis.as<uint8_t>();
+            if (batches) {
+                if (cw) hipLaunchKernelGGL(k_ir_trace<true>, gridT, blk, 0, s, w, dscene, v0, vb, vis, work, spill, sstride, ctr);
+                else if (c->ir_packet && c->stack_need <= (uint32_t)kPacketStack) hipLaunchKernelGGL(k_ir_trace_packet, dim3(c->resident_packet_blocks), blk, 0, s, w, dscene, v0, vb, vis, work, spill, sstride);
+                else hipLaunchKernelGGL(k_ir_trace<false>, gridT, blk, 0, s, w, dscene, v0, vb, vis, work, spill, sstride, (unsigned long long*)nullptr);
+            }
+            hipLaunchKernelGGL(k_ir_shade, gridQ, blk, 0, s, w, dscene, v0, vb, (const uint8_t*)vis, bi == 0 ? 1 : 0, bi + 1u >= batches ? 1 : 0);
+        }
         if (film_wait && hipStreamWaitEvent(s, film_wait, 0) != hipSuccess) return RTX_ERR_HIP;
         launch_film_accumulate(w, (int)st.filter, gridP, blk, s);
         c->stats.samples += (uint64_t)w.W * w.H;

@@ -294,6 +294,64 @@ def test_instant_radiosity_sample_split_equals_single_rank(pkg, lib, core, scene
     assert np.allclose(acc, full, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("mode", [2, 1], ids=["spp", "tiles"])
+def test_light_tracing_split_equals_single_rank(pkg, lib, core, scenes, mode):
+    """Light tracing (RTBase/Renderer.h:379-411) over two ranks: the light paths are keyed on (pixel slot, global
+    sample index), every rank traces its share of them (its sample indices over the whole film, or the paths of its
+    tiles) and splats anywhere on the film; the sum of the two films is the single-rank film of the same global
+    samples but for the summation order of the splats."""
+    scene, cam_kw = scenes.mixed_scene(32, (128, 64)), scenes.mixed_camera()
+    kw = dict(algorithm=pkg.AL_LIGHT_TRACE, total_spp=6, seed=53, can_hit_light=1)
+    core.upload_scene(scene); core.set_camera(pkg.look_at(lib, width=128, height=72, **cam_kw))
+    core.set_settings(pkg.make_settings(**kw)); core.clear(); core.render_passes(6)
+    full = core.film()[0]
+    assert full.sum() > 0
+    acc = np.zeros_like(full)
+    for rank in range(2):
+        core.set_settings(pkg.make_settings(shard_mode=mode, shard_rank=rank, shard_world=2, **kw)); core.clear()
+        core.render_passes(3 if mode == 2 else 6)
+        part = core.film()[0]
+        assert part.sum() > 0
+        acc += part
+    assert np.allclose(acc, full, rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["spp", "tiles"])
+def test_light_tracing_render_sharded_two_contexts_one_gpu(pkg, lib, core, scenes, mode):
+    """The same through multigpu.render_sharded with two contexts on the one GPU standing in for two ranks: both end
+    with the complete film and SPP = total_spp."""
+    import torch
+    mg = importlib.import_module("ray-tracer_amd.multigpu")
+    torch.cuda.set_device(0)
+    scene, cam = scenes.cornell_box("mixed"), pkg.look_at(lib, width=64, height=48, **scenes.cornell_camera())
+    base = pkg.make_settings(algorithm=pkg.AL_LIGHT_TRACE, total_spp=5, seed=59, can_hit_light=1)
+    core.upload_scene(scene); core.set_camera(cam); core.set_settings(base); core.clear(); core.render_passes(5)
+    want = core.film()[0]
+    world = 2
+    dist = _LocalDist(world, torch)
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            dist.local.rank = rank
+            c = pkg.Core(0, lib)
+            c.upload_scene(scene); c.set_camera(cam)
+            c.set_settings(mg.shard_settings(base, rank, world, mode)); c.clear()
+            mg.render_sharded(mg.CoreTarget(c, torch), base, dist, rank, world, mode)
+            out[rank] = c.film()
+            c.close()
+        except Exception as e:
+            errs.append(e)
+            dist.bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+    (f0, s0, _), (f1, s1, _) = out
+    assert s0 == s1 == 5 and np.array_equal(f0, f1)
+    assert want.sum() > 0 and np.allclose(f0, want, rtol=2e-5, atol=1e-6)
+
+
 # ---- deepest traversal stacks ----------------------------------------------------------------------
 
 def test_deep_caterpillar_tree_uses_the_global_stack_part(pkg, lib, core, orc, scenes):

@@ -18,6 +18,9 @@ CASES = {
     "plain": (dict(total_spp=5, seed=17), 48, 40),
     "adaptive": (dict(total_spp=12, init_spp=4, adaptive_sampling=1, seed=19), 64, 48),
     "radiosity": (dict(total_spp=4, seed=23, algorithm=2, num_threads=3, vpl_rays_per_tile=2), 40, 32),
+    # light tracing (RTBase/Renderer.h:379-411): splats land anywhere on the film, so the ranks split the light paths
+    # (by samples, or by the tiles whose pixels stand for the paths) and every film is a partial sum of the whole image
+    "light": (dict(total_spp=5, seed=29, algorithm=1, can_hit_light=1), 40, 32),
 }
 
 
@@ -92,7 +95,7 @@ def _worker(rank, world, port, mode, case, out_dir):
 
 
 @pytest.mark.parametrize("mode,case", [("tiles", "plain"), ("spp", "plain"), ("tiles", "adaptive"), ("spp", "adaptive"),
-                                       ("tiles", "radiosity"), ("spp", "radiosity")])
+                                       ("tiles", "radiosity"), ("spp", "radiosity"), ("spp", "light"), ("tiles", "light")])
 def test_two_rank_partition_matches_single_rank(tmp_path, mode, case, pkg, orc, scenes):
     import torch.multiprocessing as mp
     port = 29500 + (os.getpid() * 7 + hash((mode, case))) % 2000
@@ -114,7 +117,10 @@ def test_two_rank_partition_matches_single_rank(tmp_path, mode, case, pkg, orc, 
         else:
             # the summed film of the first initSPP samples differs from the sequential sum in the last bits
             assert np.abs(tiles[0].astype(np.int64) - want_tiles.astype(np.int64)).max() <= 1
-    if mode == "tiles":
+    if case == "light":
+        # the same splats in another summation order
+        assert want.sum() > 0 and np.allclose(films[0], want, rtol=1e-5, atol=1e-6)
+    elif mode == "tiles":
         assert np.array_equal(films[0], want)
     elif case == "adaptive":
         same = np.repeat(np.repeat((tiles[0] == want_tiles).reshape((h + 15) // 16, (w + 15) // 16), 16, 0), 16, 1)[:h, :w]

@@ -1,12 +1,58 @@
-import importlib, time, sys
-sys.path.insert(0, "/root/repo")
-pkg = importlib.import_module("ray-tracer_amd"); scenes = importlib.import_module("ray-tracer_amd.scenes")
-lib = pkg.load_library(); core = pkg.Core(0, lib)
-for name, sc, cam in (("cornell", scenes.cornell_box("diffuse"), scenes.cornell_camera()), ("mixed", scenes.mixed_scene(128), scenes.mixed_camera())):
-    core.upload_scene(sc); core.set_camera(pkg.look_at(lib, width=1920, height=1080, **cam))
-    for paths in (4, 22):
-        core.set_settings(pkg.make_settings(algorithm=pkg.AL_INSTANT_RADIOSITY, total_spp=8, max_bounces=5, vpl_rays_per_tile=1, num_threads=paths))
-        core.clear(); core.render_passes(1); core.clear(); core.reset_stats()
-        t = time.time(); core.render_passes(4); dt = (time.time() - t) / 4
-        st = core.stats()
-        print(name, "light paths", paths, "ms/pass %.2f" % (dt * 1e3), {k: getattr(st, k) for k, _ in st._fields_ if "ray" in k or "vpl" in k}, flush=True)
+#!/usr/bin/env python3
+"""Instant radiosity at 1080p: milliseconds per pass, valid VPLs per pass and gather segments per pass.
+
+    python tools/ir_timing.py [--paths 128] [--passes 8] [--scenes cornell,mixed]
+
+Light paths per pass = num_threads x vpl_rays_per_tile (RTBase/Renderer.h:174,283); 128 = 8 x 16."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--paths", default="128")
+    ap.add_argument("--passes", type=int, default=8)
+    ap.add_argument("--scenes", default="cornell,mixed")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-count", action="store_true", help="skip the instrumented passes (for runs under a profiler)")
+    args = ap.parse_args()
+    pkg = importlib.import_module("ray-tracer_amd")
+    scenes = importlib.import_module("ray-tracer_amd.scenes")
+    lib = pkg.load_library()
+    core = pkg.Core(0, lib)
+    table = {"cornell": (lambda: scenes.cornell_box("diffuse"), scenes.cornell_camera), "mixed": (lambda: scenes.mixed_scene(128), scenes.mixed_camera)}
+    for name in args.scenes.split(","):
+        make, cam = table[name]
+        core.upload_scene(make())
+        core.set_camera(pkg.look_at(lib, width=args.width, height=args.height, **cam()))
+        for paths in (int(p) for p in args.paths.split(",")):
+            threads = 8 if paths % 8 == 0 else 1
+            core.set_settings(pkg.make_settings(algorithm=pkg.AL_INSTANT_RADIOSITY, total_spp=100000, max_bounces=5, vpl_rays_per_tile=paths // threads, num_threads=threads))
+            core.clear(); core.render_passes(2); core.clear()
+            t = time.perf_counter()
+            for _ in range(args.passes):
+                core.render_passes(1)
+            single = (time.perf_counter() - t) / args.passes
+            core.clear()
+            t = time.perf_counter(); core.render_passes(args.passes); piped = (time.perf_counter() - t) / args.passes
+            out = {"scene": name, "resolution": [args.width, args.height], "light_paths": paths, "single_pass_ms": round(single * 1e3, 3),
+                   "pipelined_ms_per_pass": round(piped * 1e3, 3), "passes_per_s": round(1.0 / piped, 1)}
+            if not args.no_count:
+                w = core.count_render_work(2)
+                out.update({"vpls_per_pass": w["vpls"] / 2, "gather_segments_per_pass": w["gather_segments"] / 2,
+                            "gather_gsegments_per_s": round(w["gather_segments"] / 2 / piped / 1e9, 2),
+                            "nodes_per_ray": round(w["nodes"] / max(1, w["closest_rays"] + w["shadow_rays"]), 2),
+                            "tris_per_ray": round(w["tris"] / max(1, w["closest_rays"] + w["shadow_rays"]), 2)})
+            print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
