@@ -81,7 +81,7 @@ def main():
 
     pkg = importlib.import_module("ray-tracer_amd")
     scenes = importlib.import_module("ray-tracer_amd.scenes")
-    lib = pkg.load_library()
+    lib = pkg.load_library(pkg.LIB_TUNING_PATH if args.variants else "")     # the schedules under test exist in the tuning build only
     core = pkg.Core(local_rank, lib)
     # the core keeps its own (non-blocking) stream: kernels are timed with HIP events on that stream
     # (rtx_timer_*), and every hand-over between torch's work and the core's is a device-wide

@@ -238,6 +238,8 @@ int rtx_film_allreduce(rtx_ctx* ctx, const rtx_collective* coll);
  * more, when the global sample count reaches initSPP: tile split - every rank computes the targets of its own tiles
  * (complete pixels) and the tables are summed; sample split - the films are summed, every rank computes the same
  * targets from the sum (calculateTileSamples, RTBase/Renderer.h:643-671) and carries on with its own partial film.
+ * (a tile split with a Gaussian or Mitchell filter, whose splats cross tile borders, does the same). The film must be
+ * empty when the call starts (SPP == 0, i.e. after rtx_clear or rtx_set_camera): RTX_ERR_STATE otherwise.
  * shard_world 1 needs no collective (coll may be NULL) and equals rtx_render_passes(total_spp). Blocking. */
 int rtx_render_sharded(rtx_ctx* ctx, const rtx_collective* coll);
 

@@ -16,6 +16,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librtx.so")
+LIB_TUNING_PATH = os.path.join(_HERE, "librtx_tuning.so")
 
 AL_PATH_TRACE, AL_LIGHT_TRACE, AL_INSTANT_RADIOSITY = 0, 1, 2
 DM_ALGORITHM, DM_NORMALS, DM_ALBEDO, DM_DIRECT = 0, 1, 2, 3
@@ -156,7 +157,11 @@ def material(type=BSDF_DIFFUSE, texture=0, emission=(0, 0, 0), eta=(0, 0, 0), k=
                     roughness, int_ior, ext_ior)
 
 
-def load_library(path: str = LIB_PATH) -> C.CDLL:
+def load_library(path: str = "") -> C.CDLL:
+    """The shipped library, or with RTX_LIBRARY=tuning in the environment (or path=LIB_TUNING_PATH) its tuning build:
+    the same code plus the schedules under test and the measurement switches that tools/ use."""
+    if not path:
+        path = LIB_TUNING_PATH if os.environ.get("RTX_LIBRARY") == "tuning" else LIB_PATH
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: build it first (python -c 'import __graft_entry__ as g; g.build()'); "
                            "there is no CPU fallback")

@@ -32,6 +32,15 @@ int fail(int code, const char* fmt, ...)
 
 namespace {
 
+// Switches that exist for measurements only (schedules under test, grid sizes, counters on stderr) are read in the
+// tuning build of the library (-DRTX_TUNING, librtx_tuning.so, used by tools/ and the A/B legs of bench.py); the
+// shipped library has one schedule and reads none of them.
+#ifdef RTX_TUNING
+const char* tuning_env(const char* name) { return getenv(name); }
+#else
+const char* tuning_env(const char*) { return nullptr; }
+#endif
+
 template <class T>
 int upload(DevBuf& b, const std::vector<T>& v, hipStream_t s)
 {
@@ -165,7 +174,7 @@ static int create_resources(rtx_ctx* c, int device)
 {
     c->device = device;
     c->variant = 1;
-    if (const char* v = getenv("RTX_VARIANT")) c->variant = atoi(v);
+    if (const char* v = tuning_env("RTX_VARIANT")) c->variant = atoi(v);
     { int rc = resolve_scratch(device, &c->na_scratch); if (rc) return rc; }
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
@@ -177,9 +186,9 @@ static int create_resources(rtx_ctx* c, int device)
         c->resident_blocks = std::max(1, std::min(kMaxGridBlocks, per_cu * prop.multiProcessorCount));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_ir_trace_packet, kBlock, 0));
         c->resident_packet_blocks = std::max(1, std::min(kMaxGridBlocks, per_cu * prop.multiProcessorCount));
-        if (const char* v = getenv("RTX_IR_PACKET")) c->ir_packet = atoi(v);
-        if (const char* g = getenv("RTX_GRID")) c->resident_blocks = std::max(1, std::min(kMaxGridBlocks, atoi(g)));   // tuning override
-        if (getenv("RTX_DEBUG_COUNTERS")) fprintf(stderr, "[rtx] %d CUs x %d resident traversal workgroups\n", prop.multiProcessorCount, per_cu);
+        if (const char* v = tuning_env("RTX_IR_PACKET")) c->ir_packet = atoi(v);
+        if (const char* g = tuning_env("RTX_GRID")) c->resident_blocks = std::max(1, std::min(kMaxGridBlocks, atoi(g)));   // tuning override
+        if (tuning_env("RTX_DEBUG_COUNTERS")) fprintf(stderr, "[rtx] %d CUs x %d resident traversal workgroups\n", prop.multiProcessorCount, per_cu);
     }
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
@@ -193,10 +202,10 @@ static int create_resources(rtx_ctx* c, int device)
         HIP_TRY(hipEventCreateWithFlags(&c->ev_shade[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_shadow[i], hipEventDisableTiming));
     }
-    if (const char* v = getenv("RTX_OVERLAP")) c->overlap = atoi(v) != 0;
-    if (const char* v = getenv("RTX_MERGE")) c->merge_shadow = atoi(v) != 0;
-    if (const char* v = getenv("RTX_RAYS_PER_BLOCK")) c->rays_per_block = std::max(1, std::min(kBlock, atoi(v)));
-    if (const char* v = getenv("RTX_PIPELINE")) c->pipeline = std::max(1, std::min(kPipeline, atoi(v)));
+    if (const char* v = tuning_env("RTX_OVERLAP")) c->overlap = atoi(v) != 0;
+    if (const char* v = tuning_env("RTX_MERGE")) c->merge_shadow = atoi(v) != 0;
+    if (const char* v = tuning_env("RTX_RAYS_PER_BLOCK")) c->rays_per_block = std::max(1, std::min(kBlock, atoi(v)));
+    if (const char* v = tuning_env("RTX_PIPELINE")) c->pipeline = std::max(1, std::min(kPipeline, atoi(v)));
     HIP_TRY(c->b_counters.ensure(4 * (1 + 2) * kWorkSlotWords));   // instrumentation counters, then the work-counter slots of the closest-hit and visibility launches
     // RayTracer's defaults, RTBase/Settings.h:40-61
     rtx_settings& s = c->settings;
@@ -285,8 +294,8 @@ int rtx_upload_scene(rtx_ctx* c, const rtx_scene_desc* d)
     ds.scene_radius = h.scene_radius;
     ds.spread_below = 32;
     ds.fine_per_wave = 192;
-    if (const char* v = getenv("RTX_FINE")) ds.fine_per_wave = (uint32_t)std::max(0, std::min(4096, atoi(v)));   // tuning override
-    if (const char* v = getenv("RTX_SPREAD")) ds.spread_below = (uint32_t)std::max(0, std::min(32, atoi(v)));   // tuning override
+    if (const char* v = tuning_env("RTX_FINE")) ds.fine_per_wave = (uint32_t)std::max(0, std::min(4096, atoi(v)));   // tuning override
+    if (const char* v = tuning_env("RTX_SPREAD")) ds.spread_below = (uint32_t)std::max(0, std::min(32, atoi(v)));   // tuning override
 
     // traversal stack: at most three pushes per wide level, or one pending node per binary
     // level on the exact path; entries beyond the LDS part go to global memory
@@ -503,6 +512,7 @@ int rtx_trace_closest_device(rtx_ctx* c, const rtx_ray* rays, size_t n, rtx_hit*
     if (n == 0) return RTX_OK;
     if (!rays || !hits) return fail(RTX_ERR_INVALID, "null buffer");
     if (n > 0xF0000000ull) return fail(RTX_ERR_INVALID, "too many rays in one call");
+#ifdef RTX_TUNING
     if (c->variant == 0) {
         // A/B baseline: static assignment of rays to lanes (RTX_VARIANT=0)
         hipLaunchKernelGGL(k_closest_static, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, c->dscene, rays, (uint32_t)n, hits,
@@ -515,7 +525,9 @@ int rtx_trace_closest_device(rtx_ctx* c, const rtx_ray* rays, size_t n, rtx_hit*
                            (uint32_t)n, hits, c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), wc);
         RTX_AB(2, 20, 4, 28, 12, 4, 0) RTX_AB(3, 16, 4, 24, 12, 4, 1) RTX_AB(4, 24, 4, 32, 12, 4, 1)  // no tail sharing; neighbours of the default (20 idle lanes to refill, 28 leaf lanes to stop descending)
 #undef RTX_AB
-    } else {
+    } else
+#endif
+    {
         uint32_t* wc = c->b_counters.as<uint32_t>() + kWorkSlotWords;
         HIP_TRY(hipMemsetAsync(wc, 0, kWorkSlotWords * 4, c->stream));
         hipLaunchKernelGGL(k_closest<false>, dim3(dyn_grid_for(c, n)), dim3(kBlock), 0, c->stream, c->dscene, rays, (const uint32_t*)nullptr,
@@ -644,12 +656,14 @@ int rtx_trace_visible_device(rtx_ctx* c, const float* p1p2, size_t n, uint8_t* v
     if (n > 0xF0000000ull) return fail(RTX_ERR_INVALID, "too many segments in one call");
     uint32_t* wc = c->b_counters.as<uint32_t>() + 2 * kWorkSlotWords;
     HIP_TRY(hipMemsetAsync(wc, 0, kWorkSlotWords * 4, c->stream));
+#ifdef RTX_TUNING
     if (c->variant >= 2) {
 #define RTX_ABV(V, R, U, S, SH) if (c->variant == V) hipLaunchKernelGGL((k_visible_ab<R, U, S, SH>), dim3(dyn_grid_for(c, n)), dim3(kBlock), 0, c->stream, c->dscene, p1p2, \
                            (uint32_t)n, vis, c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), wc);
         RTX_ABV(2, 20, 4, 28, 0) RTX_ABV(3, 16, 4, 24, 1) RTX_ABV(4, 24, 4, 32, 1)   // no tail sharing; neighbours of the default thresholds
 #undef RTX_ABV
     } else
+#endif
     hipLaunchKernelGGL(k_visible, dim3(dyn_grid_for(c, n)), dim3(kBlock), 0, c->stream, c->dscene, p1p2, (uint32_t)n, vis,
                        c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), wc);
     HIP_TRY(hipGetLastError());
@@ -694,7 +708,7 @@ int rtx_count_closest_work(rtx_ctx* c, const rtx_ray* rays, size_t n, uint64_t* 
     unsigned long long h[6];
     HIP_TRY(hipMemcpyAsync(h, c->b_counters.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (getenv("RTX_DEBUG_COUNTERS")) {
+    if (tuning_env("RTX_DEBUG_COUNTERS")) {
         // distribution of the dependent steps of a ray (node visits + groups of four triangle tests): the slowest
         // ray bounds how long a launch lasts after its queue has run dry
         std::vector<rtx_hit> hh(n);
@@ -706,7 +720,7 @@ int rtx_count_closest_work(rtx_ctx* c, const rtx_ray* rays, size_t n, uint64_t* 
         fprintf(stderr, "[rtx] dependent steps per ray: mean %.1f, median %u, p90 %u, p99 %u, p99.9 %u, max %u\n", sum / (double)n, steps[n / 2], steps[n * 9 / 10],
                 steps[n * 99 / 100], steps[(size_t)(n * 0.999)], steps[n - 1]);
     }
-    if (getenv("RTX_DEBUG_COUNTERS"))
+    if (tuning_env("RTX_DEBUG_COUNTERS"))
         fprintf(stderr, "[rtx] lane node visits %llu, lane tri tests %llu; wave inner trips %llu, wave tri trips %llu, wave outer trips %llu\n", h[0], h[1], h[2], h[3], h[4]);
     *nodes = h[0]; *tris = h[1];
     if (tri_groups) *tri_groups = h[5];
@@ -743,6 +757,19 @@ int rtx_count_render_work(rtx_ctx* c, int n_passes, uint64_t out[8])
     unsigned long long h[8];
     HIP_TRY(hipMemcpy(h, c->b_counters.p, sizeof h, hipMemcpyDeviceToHost));
     out[2] = h[0]; out[3] = h[1]; out[5] = h[5]; out[6] = h[6]; out[1] += h[6];
+#ifdef RTX_TUNING
+    {
+        // (the instrumented passes above ran the per-lane gather; one more plain pass for the packet walk's statistics)
+        HIP_TRY(hipMemset(c->b_counters.as<unsigned long long>() + 8, 0, 6 * 8));
+        int rc = wavefront_render_pass(c, 0, c->stream, nullptr, nullptr, false);
+        if (rc) return fail(rc, "render pass failed");
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        unsigned long long p[6];
+        HIP_TRY(hipMemcpy(p, c->b_counters.as<unsigned long long>() + 8, sizeof p, hipMemcpyDeviceToHost));
+        if (p[4]) fprintf(stderr, "[rtx] packet walk: %llu packets of %.1f segments; per packet %.2f node steps with %.1f lanes, %.2f triangle steps with %.1f lanes\n", p[4], (double)p[5] / p[4],
+                          (double)p[0] / p[4], p[0] ? (double)p[1] / p[0] : 0.0, (double)p[2] / p[4], p[2] ? (double)p[3] / p[2] : 0.0);
+    }
+#endif
     return RTX_OK;
 }
 

@@ -128,6 +128,9 @@ int rtx_render_sharded(rtx_ctx* c, const rtx_collective* coll)
 {
     CTX_TRY(c);
     if (!c->have_scene || !c->have_camera) return fail(RTX_ERR_STATE, "scene and camera must be set before rendering");
+    // The passes below are counted from zero: with samples already in the film the adaptive meeting would come at the
+    // wrong pass (or never) and the film would hold more samples than SPP says afterwards.
+    if (c->spp != 0) return fail(RTX_ERR_STATE, "rtx_render_sharded starts from an empty film: SPP is %d, call rtx_clear first", c->spp);
     const rtx_settings st = c->settings;                 // adaptive_sampling / init_spp already gated as RayTracer::init does
     const uint32_t world = (uint32_t)std::max(1, st.shard_world);
     if (world > 1 && st.shard_mode == 0) return fail(RTX_ERR_STATE, "shard_world %u with shard_mode 0: set shard_mode 1 (tiles) or 2 (samples)", world);
@@ -139,15 +142,19 @@ int rtx_render_sharded(rtx_ctx* c, const rtx_collective* coll)
     if (world > 1 && adaptive) {
         const uint32_t n_init = passes_of_rank(st.init_spp, st);
         if ((rc = rtx_render_passes(c, (int)n_init))) return rc;
-        if (st.shard_mode == 1) {
+        if (st.shard_mode == 1 && st.filter == RTX_FT_BOX) {
             // every rank has computed targets for all tiles from its own film; only those of its own tiles count
+            // (box filter: a tile's pixels are complete on its owner but for the few samples whose x + r rounds up
+            // across a tile border, which can move a target by one sample)
             hipLaunchKernelGGL(k_keep_own_tiles, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, c->stream, c->b_tile_samples.as<uint32_t>(), (uint32_t)n_tiles,
                                (uint32_t)st.shard_rank, world);
             HIP_TRY(hipGetLastError());
             if ((rc = coll->allreduce_sum_u32(coll->user, c->b_tile_samples.as<uint32_t>(), n_tiles, c->stream))) return rc;
         } else {
             // the variance is not linear in the per-rank sums: sum the films of the first initSPP samples, compute the
-            // targets from the sum on every rank (identical input, identical targets), put the own partial film back
+            // targets from the sum on every rank (identical input, identical targets), put the own partial film back.
+            // Tile split with a Gaussian or Mitchell filter takes this way too: their splats reach two pixels into
+            // the neighbouring tiles (RTBase/Imaging.h:324-339), so no tile is complete on its owner.
             HIP_TRY(c->b_io_a.ensure(n_film * sizeof(float)));
             HIP_TRY(hipMemcpyAsync(c->b_io_a.p, c->b_film.p, n_film * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
             if ((rc = coll->allreduce_sum_f32(coll->user, c->b_film.as<float>(), n_film, c->stream))) return rc;

@@ -206,10 +206,14 @@ std::string prepare_scene(const rtx_scene_desc& d, HostScene& hs, const Bvh2Buil
     // the traversal kernels address nodes by a 32-bit byte offset (128 bytes per node)
     if (hs.bvh4.nodes.size() >= (1u << 25)) return "too many BVH nodes (limit 2^25 - 1 four-wide nodes)";
     auto t3 = std::chrono::steady_clock::now();
+#ifdef RTX_TUNING
     if (getenv("RTX_DEBUG_COUNTERS"))
         fprintf(stderr, "[rtx] scene preparation: triangles %.1f ms, binary BVH (%s) %.1f ms, 4-wide layout %.1f ms\n",
                 std::chrono::duration<float, std::milli>(t1 - t0).count(), build ? "device" : "host",
                 std::chrono::duration<float, std::milli>(t2 - t1).count(), std::chrono::duration<float, std::milli>(t3 - t2).count());
+#else
+    (void)t0; (void)t1; (void)t2; (void)t3;
+#endif
     hs.tris.resize(d.n_triangles);
     parallel_ranges(d.n_triangles, [&](uint64_t rb, uint64_t re) { for (uint64_t p = rb; p < re; p++) {
         const uint32_t id = hs.bvh4.order[p]; const TriPrep& t = prep[id]; TriIsect& o = hs.tris[p];

@@ -46,8 +46,9 @@ __device__ __forceinline__ rtx_hit make_hit(const DeviceScene& sc, const HitRec&
     return h;
 }
 
+#ifdef RTX_TUNING
 // Reference schedule: one ray per lane, grid-stride, each wave finishes its 64 rays before
-// taking the next 64. Kept as the A/B baseline of the dynamic schedule (RTX_VARIANT=0).
+// taking the next 64. Kept as the A/B baseline of the dynamic schedule (RTX_VARIANT=0, tuning build only).
 __global__ __launch_bounds__(kBlock) void k_closest_static(DeviceScene sc, const rtx_ray* __restrict__ rays, uint32_t n, rtx_hit* __restrict__ hits,
                                                            uint2* spill, uint32_t spill_stride)
 {
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(kBlock) void k_closest_static(DeviceScene sc, const
         hits[i] = make_hit(sc, best);
     }
 }
+#endif
 
 // ---- closest hit: Scene::traverse, RTBase/Scene.h:137 -> BVHTree::traverse, Geometry.h:506-566 ----
 struct ClosestPolicy {
@@ -90,7 +92,8 @@ __global__ __launch_bounds__(kBlock) void k_closest(DeviceScene sc, const rtx_ra
     traverse_dyn<ClosestPolicy, kModeClosest, COUNT, kRefillClosest, kBlock, kLdsStack, kTriUnroll, kLeafLanesClosest, COUNT ? 0 : kShare>(sc, stk, n_dev ? *n_dev : n_host, work_counter, pol, counters, &ts);
 }
 
-// Schedules under test (A/B harness only)
+#ifdef RTX_TUNING
+// Schedules under test (A/B harness, tuning build only)
 template <int REFILL, int UNROLL, int SCHED, int LDS_N, int WAVES, int SHARE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_closest_ab(DeviceScene sc, const rtx_ray* __restrict__ rays, uint32_t n, rtx_hit* __restrict__ hits,
                                                        uint2* spill, uint32_t spill_stride, uint32_t* work_counter)
@@ -101,6 +104,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, W
     __shared__ TailShare<kBlock> ts;
     traverse_dyn<ClosestPolicy, kModeClosest, false, REFILL, kBlock, LDS_N, UNROLL, SCHED, SHARE>(sc, stk, n, work_counter, pol, nullptr, &ts);
 }
+#endif
 
 // ---- visibility: Scene::visible, RTBase/Scene.h:170-178 -> traverseVisible, Geometry.h:568-610 ----
 // A segment whose ray misses the root box is NOT visible (Geometry.h:571-572).
@@ -120,7 +124,8 @@ __global__ __launch_bounds__(kBlock) void k_visible(DeviceScene sc, const float*
     traverse_dyn<VisiblePolicy, kModeAny, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, n, work_counter, pol, nullptr, &ts);
 }
 
-// Schedules under test (A/B harness only)
+#ifdef RTX_TUNING
+// Schedules under test (A/B harness, tuning build only)
 template <int REFILL, int UNROLL, int SCHED, int SHARE>
 __global__ __launch_bounds__(kBlock) void k_visible_ab(DeviceScene sc, const float* __restrict__ p1p2, uint32_t n, uint8_t* __restrict__ visible,
                                                        uint2* spill, uint32_t spill_stride, uint32_t* work_counter)
@@ -131,6 +136,7 @@ __global__ __launch_bounds__(kBlock) void k_visible_ab(DeviceScene sc, const flo
     __shared__ TailShare<kBlock> ts;
     traverse_dyn<VisiblePolicy, kModeAny, false, REFILL, kBlock, kLdsStack, UNROLL, SCHED, SHARE>(sc, stk, n, work_counter, pol, nullptr, &ts);
 }
+#endif
 
 // One segment, inside a kernel that loops over segments per lane (the VPL gather)
 template <int BLOCK, int LDS_N>

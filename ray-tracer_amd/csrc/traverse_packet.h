@@ -30,6 +30,8 @@ template <int BLOCK>
 struct PacketStacks {
     uint32_t ref[BLOCK / 64][kPacketStack];
     unsigned long long mask[BLOCK / 64][kPacketStack];
+    uint32_t src[BLOCK / 64][64];        // leaf step: the lanes of the current mask, packed
+    uint32_t hit[BLOCK / 64][64];        // leaf step: lane l's segment was found occluded by another lane (zero between uses)
 };
 
 __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
@@ -37,12 +39,17 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
     return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
 }
 
+// ceil(2^16 / n) for n = 1 .. 16: floor(q / n) == (q * kInv16[n]) >> 16 for q < 4096
+__device__ const uint32_t kInv16[17] = {0, 65536, 32768, 21846, 16384, 13108, 10923, 9363, 8192, 7282, 6554, 5958, 5462, 5042, 4682, 4370, 4096};
+
 // One segment per lane (has == false: the lane holds none). Returns true for lanes whose segment is NOT visible:
 // occluded, or the ray misses the root box (Geometry.h:571-572). All lanes of the wave must call this together.
 // COUNT: nodes / tris receive what the lane's own segment visited (the numbers a per-lane walk would count).
+// wave_stats (tuning builds, may be null): [0] node steps, [1] lanes in their masks, [2] triangle steps, [3] lanes in theirs
 template <int BLOCK, bool COUNT>
 __device__ __forceinline__ bool packet_occluded(const DeviceScene& sc, PacketStacks<BLOCK>& ps, LaneStack<BLOCK, 0>& exact_stack, bool has,
-                                                float ox, float oy, float oz, float dx, float dy, float dz, float maxT, uint32_t* nodes, uint32_t* tris)
+                                                float ox, float oy, float oz, float dx, float dy, float dz, float maxT, uint32_t* nodes, uint32_t* tris,
+                                                uint32_t* wave_stats = nullptr)
 {
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;                                    // Ray::init, Geometry.h:25
@@ -53,10 +60,16 @@ __device__ __forceinline__ bool packet_occluded(const DeviceScene& sc, PacketSta
     uint32_t* s_ref = ps.ref[wv]; unsigned long long* s_mask = ps.mask[wv];
     uint32_t sp = 0;
     unsigned long long done = 0ull;                          // lanes that have found an occluder
-    {
-        const unsigned long long m0 = __ballot(root && finite);
-        if (m0 != 0ull) { s_ref[0] = 0u; s_mask[0] = m0; sp = 1; }
-    }
+    const unsigned long long m0 = __ballot(root && finite);
+    if (m0 != 0ull) { s_ref[0] = 0u; s_mask[0] = m0; sp = 1; }
+    // Segments of one packet mostly travel the same way along every axis. Then the near plane of a box (the low one
+    // for a ray that travels up the axis, the high one otherwise) is the same plane for the whole wave and is picked
+    // by the address the scalar load reads, and (near - o) * inv <= (far - o) * inv holds in floating point too
+    // (subtraction and multiplication by a finite reciprocal of one sign are monotone), so tentry / texit are the
+    // same numbers as the minima and maxima of the two products that the general form takes.
+    const unsigned long long negx = __ballot(ix < 0.0f) & m0, negy = __ballot(iy < 0.0f) & m0, negz = __ballot(iz < 0.0f) & m0;
+    const bool one_way = (negx == 0ull || negx == m0) && (negy == 0ull || negy == m0) && (negz == 0ull || negz == m0);
+    const uint32_t offx = negx ? 12u : 0u, offy = negy ? 16u : 4u, offz = negz ? 20u : 8u;     // float offsets of the near planes inside a Node4
     ConstFloat* nodes4 = (ConstFloat*)sc.nodes4;
     ConstFloat* trif = (ConstFloat*)sc.tris;
     while (sp > 0) {
@@ -69,36 +82,87 @@ __device__ __forceinline__ bool packet_occluded(const DeviceScene& sc, PacketSta
             ConstFloat* np = nodes4 + (size_t)ref * 32;          // Node4: lo[axis][slot], hi[axis][slot], child[4]
             ConstWord* cp = (ConstWord*)(np + 24);
             if (COUNT && in) (*nodes)++;
+            if (wave_stats) { wave_stats[0]++; wave_stats[1] += (uint32_t)__popcll(mask); }
             const uint32_t cr[4] = {cp[0], cp[1], cp[2], cp[3]};
-            const float lx[4] = {np[0], np[1], np[2], np[3]}, ly[4] = {np[4], np[5], np[6], np[7]}, lz[4] = {np[8], np[9], np[10], np[11]};
-            const float hx[4] = {np[12], np[13], np[14], np[15]}, hy[4] = {np[16], np[17], np[18], np[19]}, hz[4] = {np[20], np[21], np[22], np[23]};
+            if (one_way) {
+                ConstFloat* nx = np + offx; ConstFloat* ny = np + offy; ConstFloat* nz = np + offz;
+                ConstFloat* fx = np + (offx ^ 12u); ConstFloat* fy = np + (offy ^ 20u); ConstFloat* fz = np + (offz ^ 28u);
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                if (cr[c] == kEmptySlot) continue;          // (wave-uniform)
-                // no NaN can occur here (finite reciprocals), so plain min / max equal the reference's selects
-                const float t0x = (lx[c] - ox) * ix, t1x = (hx[c] - ox) * ix;
-                const float t0y = (ly[c] - oy) * iy, t1y = (hy[c] - oy) * iy;
-                const float t0z = (lz[c] - oz) * iz, t1z = (hz[c] - oz) * iz;
-                const float tentry = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
-                const float texit = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-                const bool hit = in && !(tentry > texit || texit < 0) && !(tentry > bound);
-                const unsigned long long hm = __ballot(hit);
-                if (hm != 0ull) { s_ref[sp] = cr[c]; s_mask[sp] = hm; sp++; }
+                for (int c = 0; c < 4; c++) {
+                    if (cr[c] == kEmptySlot) continue;          // (wave-uniform)
+                    const float tentry = fmaxf(fmaxf((nx[c] - ox) * ix, (ny[c] - oy) * iy), (nz[c] - oz) * iz);
+                    const float texit = fminf(fminf((fx[c] - ox) * ix, (fy[c] - oy) * iy), (fz[c] - oz) * iz);
+                    const bool hit = in && !(tentry > texit || texit < 0) && !(tentry > bound);
+                    const unsigned long long hm = __ballot(hit);
+                    if (hm != 0ull) { s_ref[sp] = cr[c]; s_mask[sp] = hm; sp++; }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    if (cr[c] == kEmptySlot) continue;
+                    // no NaN can occur here (finite reciprocals), so plain min / max equal the reference's selects
+                    const float t0x = (np[c] - ox) * ix, t1x = (np[12 + c] - ox) * ix;
+                    const float t0y = (np[4 + c] - oy) * iy, t1y = (np[16 + c] - oy) * iy;
+                    const float t0z = (np[8 + c] - oz) * iz, t1z = (np[20 + c] - oz) * iz;
+                    const float tentry = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+                    const float texit = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+                    const bool hit = in && !(tentry > texit || texit < 0) && !(tentry > bound);
+                    const unsigned long long hm = __ballot(hit);
+                    if (hm != 0ull) { s_ref[sp] = cr[c]; s_mask[sp] = hm; sp++; }
+                }
             }
         } else {
             const uint32_t first = ref & 0x07FFFFFFu, nt = ((ref >> 27) & 15u) + 1u;
-            for (uint32_t k = 0; k < nt; k++) {
-                if ((mask & ~done) == 0ull) break;
-                ConstFloat* tp = trif + (size_t)(first + k) * 9;
-                TriIsect T;
-#pragma unroll
-                for (int q = 0; q < 3; q++) { T.e1[q] = tp[q]; T.e2[q] = tp[3 + q]; T.v2[q] = tp[6 + q]; }
-                if (in && !occluded) {
-                    if (COUNT) (*tris)++;
-                    float t, u, v;
-                    if (tri_test(T, ox, oy, oz, dx, dy, dz, t, u, v) && t <= maxT) occluded = true;
+            const uint32_t na = (uint32_t)__popcll(mask), passes = (na * nt + 63u) / 64u;
+            if (passes * 4u < nt * 3u) {      // (a packed pass costs about a third more than a step of the loop over triangles)
+                // Few lanes reach this leaf: one lane per (segment, triangle) pair instead of one step per triangle with
+                // most lanes idle. Pair q = (the q / nt-th lane of the mask, triangle q % nt); the segment comes over by
+                // lane permutes, the result goes back through a flag per lane in LDS.
+                uint32_t* s_src = ps.src[wv]; uint32_t* s_hit = ps.hit[wv];
+                if (in) s_src[__popcll(mask & ((1ull << lane) - 1ull))] = lane;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                const uint32_t pairs = na * nt, inv = kInv16[nt];
+                bool any_hit = false;
+                for (uint32_t q0 = 0; q0 < pairs; q0 += 64u) {
+                    const uint32_t q = q0 + lane;
+                    const bool valid = q < pairs;
+                    const uint32_t r = valid ? (q * inv) >> 16 : 0u, ti = q - r * nt;
+                    const int sl = (int)s_src[r];
+                    const float sox = __shfl(ox, sl, 64), soy = __shfl(oy, sl, 64), soz = __shfl(oz, sl, 64);
+                    const float sdx = __shfl(dx, sl, 64), sdy = __shfl(dy, sl, 64), sdz = __shfl(dz, sl, 64);
+                    const float smax = __shfl(maxT, sl, 64);
+                    if (wave_stats) { wave_stats[2]++; wave_stats[3] += min(64u, pairs - q0); }
+                    bool h = false;
+                    if (valid) {
+                        const TriIsect T = sc.tris[first + ti];
+                        float t, u, v;
+                        h = tri_test(T, sox, soy, soz, sdx, sdy, sdz, t, u, v) && t <= smax;
+                        if (h) s_hit[sl] = 1u;
+                    }
+                    any_hit = any_hit || __any(h);
                 }
-                done = __ballot(occluded);
+                if (COUNT && in) (*tris) += nt;
+                if (any_hit) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    if (s_hit[lane]) { occluded = true; s_hit[lane] = 0u; }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    done = __ballot(occluded);
+                }
+            } else {
+                for (uint32_t k = 0; k < nt; k++) {
+                    if ((mask & ~done) == 0ull) break;
+                    ConstFloat* tp = trif + (size_t)(first + k) * 9;
+                    TriIsect T;
+#pragma unroll
+                    for (int q = 0; q < 3; q++) { T.e1[q] = tp[q]; T.e2[q] = tp[3 + q]; T.v2[q] = tp[6 + q]; }
+                    if (wave_stats) { wave_stats[2]++; wave_stats[3] += (uint32_t)__popcll(mask & ~done); }
+                    if (in && !occluded) {
+                        if (COUNT) (*tris)++;
+                        float t, u, v;
+                        if (tri_test(T, ox, oy, oz, dx, dy, dz, t, u, v) && t <= maxT) occluded = true;
+                    }
+                    done = __ballot(occluded);
+                }
             }
         }
     }

@@ -821,8 +821,15 @@ __global__ __launch_bounds__(kBlock) void k_ir_trace(WfPtrs w, DeviceScene sc, u
 // sweeps the pairs on one front), evaluates the geometry term of 64 pairs at a time, marks the culled ones done and
 // collects the others in a small ring in LDS; whenever the ring holds a full wave of segments (or the pairs have
 // run out) it walks them as one packet. Same result bytes as k_ir_trace.
-__global__ __launch_bounds__(kBlock) void k_ir_trace_packet(WfPtrs w, DeviceScene sc, uint32_t v0, uint32_t vb, uint8_t* vis, uint32_t work_index, uint2* spill, uint32_t spill_stride)
+#ifdef RTX_TUNING
+#define RTX_PACKET_STATS(...) __VA_ARGS__
+#else
+#define RTX_PACKET_STATS(...)
+#endif
+__global__ __launch_bounds__(kBlock) void k_ir_trace_packet(WfPtrs w, DeviceScene sc, uint32_t v0, uint32_t vb, uint8_t* vis, uint32_t work_index, uint2* spill, uint32_t spill_stride
+                                                            RTX_PACKET_STATS(, unsigned long long* stats))
 {
+    RTX_PACKET_STATS(uint32_t ws[6] = {0, 0, 0, 0, 0, 0};)
     __shared__ PacketStacks<kBlock> ps;
     __shared__ uint32_t s_ring[kBlock / 64][128];
     LaneStack<kBlock, 0> exact_stack; exact_stack.init(nullptr, spill, spill_stride);
@@ -834,7 +841,8 @@ __global__ __launch_bounds__(kBlock) void k_ir_trace_packet(WfPtrs w, DeviceScen
     uint32_t seg = blockIdx.x % (uint32_t)kWorkSegments;
     unsigned long long dry = 0ull;                  // counters this wave has found empty
     bool exhausted = n == 0u;
-    uint32_t pair_next = 0, pair_end = 0, ring_head = 0, ring_count = 0;
+    uint32_t pair_next = 0, pair_end = 0, ring_head = 0, ring_count = 0, vl0 = 0;
+    ps.hit[wv][lane] = 0u;
     const unsigned long long below = (1ull << lane) - 1ull;
     for (;;) {
         while (ring_count < 64u && !exhausted) {
@@ -851,14 +859,26 @@ __global__ __launch_bounds__(kBlock) void k_ir_trace_packet(WfPtrs w, DeviceScen
                     continue;
                 }
                 pair_next = g * 256u; pair_end = min(pair_next + 256u, n);
+                vl0 = pair_next / ng;
             }
             const uint32_t k = pair_next + lane;
             bool keep = false;
             if (k < pair_end) {
-                const uint32_t vl = k / ng, g = k - vl * ng;
+                // (all pairs of a super-chunk belong to VPL vl0 or the next one, when ng >= 256)
+                uint32_t vl = vl0, g = k - vl0 * ng;
+                if (g >= ng) { if (ng >= 256u) { vl++; g -= ng; } else { vl = k / ng; g = k - vl * ng; } }
                 const float* v = w.vplc + 10 * (size_t)(v0 + vl); const float* r = w.sseg + 6 * (size_t)g;
-                V3 wi;
-                keep = ir_geometry(ld3(r), ld3(r + 3), ld3(v), ld3(v + 3), wi) > 0;
+                // A cheap test first: the geometry term (ir_geometry) is zero when the VPL lies behind the pixel's surface or
+                // the pixel behind the VPL's. The exact decision takes the NORMALISED direction (a square root and two
+                // divisions); its two cosines differ from the plain dot products below by a positive factor and by rounding
+                // errors of at most ~1e-6 of the sum of the absolute products, so a pair whose plain dot product is more
+                // negative than 4e-6 of that sum is culled for certain. Everything else goes on and is decided exactly when
+                // its segment is set up.
+                const V3 d = ld3(v) - ld3(r), ns = ld3(r + 3), vn = ld3(v + 3);
+                const float ax = d.x * ns.x, ay = d.y * ns.y, az = d.z * ns.z, bx = d.x * vn.x, by = d.y * vn.y, bz = d.z * vn.z;
+                const float a = (ax + ay) + az, b = (bx + by) + bz;
+                const float am = (fabsf(ax) + fabsf(ay)) + fabsf(az), bm = (fabsf(bx) + fabsf(by)) + fabsf(bz);
+                keep = !(a < -4e-6f * am) && !(b > 4e-6f * bm);
                 if (!keep) vis[k] = 0;
             }
             const unsigned long long km = __ballot(keep);
@@ -869,7 +889,7 @@ __global__ __launch_bounds__(kBlock) void k_ir_trace_packet(WfPtrs w, DeviceScen
         if (ring_count == 0u) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // the ring entries other lanes wrote
         const uint32_t take = min(64u, ring_count);
-        const bool has = lane < take;
+        bool has = lane < take;
         const uint32_t k = has ? s_ring[wv][(ring_head + lane) & 127u] : 0u;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         ring_head = (ring_head + take) & 127u; ring_count -= take;
@@ -877,12 +897,18 @@ __global__ __launch_bounds__(kBlock) void k_ir_trace_packet(WfPtrs w, DeviceScen
         if (has) {
             const uint32_t vl = k / ng, g = k - vl * ng;
             const float* v = w.vplc + 10 * (size_t)(v0 + vl); const float* r = w.sseg + 6 * (size_t)g;
-            const float s[6] = {r[0], r[1], r[2], v[0], v[1], v[2]};
-            segment_to_ray(s, o, d, maxT);
+            const V3 x = ld3(r), vx = ld3(v);
+            V3 wi;
+            if (ir_geometry(x, ld3(r + 3), vx, ld3(v + 3), wi) > 0) {
+                const float s[6] = {x.x, x.y, x.z, vx.x, vx.y, vx.z};
+                segment_to_ray(s, o, d, maxT);
+            } else { vis[k] = 0; has = false; }
         }
-        const bool blocked = packet_occluded<kBlock, false>(sc, ps, exact_stack, has, o[0], o[1], o[2], d[0], d[1], d[2], maxT, nullptr, nullptr);
+        RTX_PACKET_STATS(ws[4]++; ws[5] += take;)
+        const bool blocked = packet_occluded<kBlock, false>(sc, ps, exact_stack, has, o[0], o[1], o[2], d[0], d[1], d[2], maxT, nullptr, nullptr RTX_PACKET_STATS(, stats ? ws : nullptr));
         if (has) vis[k] = blocked ? 0 : 1;
     }
+    RTX_PACKET_STATS(if (stats && lane == 0) for (int q = 0; q < 6; q++) atomicAdd(&stats[8 + q], (unsigned long long)ws[q]);)
 }
 
 // first: the sum starts at zero (otherwise it carries on from the launch before); last: divide by vpls.size(), Renderer.h:244
@@ -1171,7 +1197,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
             uint8_t* vis = b.ir_vis.as<uint8_t>();
             if (batches) {
                 if (cw) hipLaunchKernelGGL(k_ir_trace<true>, gridT, blk, 0, s, w, dscene, v0, vb, vis, work, spill, sstride, ctr);
-                else if (c->ir_packet && c->stack_need <= (uint32_t)kPacketStack) hipLaunchKernelGGL(k_ir_trace_packet, dim3(c->resident_packet_blocks), blk, 0, s, w, dscene, v0, vb, vis, work, spill, sstride);
+                else if (c->ir_packet && c->stack_need <= (uint32_t)kPacketStack) hipLaunchKernelGGL(k_ir_trace_packet, dim3(c->resident_packet_blocks), blk, 0, s, w, dscene, v0, vb, vis, work, spill, sstride RTX_PACKET_STATS(, c->b_counters.as<unsigned long long>()));
                 else hipLaunchKernelGGL(k_ir_trace<false>, gridT, blk, 0, s, w, dscene, v0, vb, vis, work, spill, sstride, (unsigned long long*)nullptr);
             }
             hipLaunchKernelGGL(k_ir_shade, gridQ, blk, 0, s, w, dscene, v0, vb, (const uint8_t*)vis, bi == 0 ? 1 : 0, bi + 1u >= batches ? 1 : 0);

@@ -147,7 +147,7 @@ class CoreTarget:
         self.torch.cuda.synchronize()
 
 
-def sync_adaptive(target, dist, world: int, mode: str, rank: int = 0):
+def sync_adaptive(target, dist, world: int, mode: str, rank: int = 0, wide_filter: bool = False):
     """Call on every rank after the pass in which the GLOBAL sample count reaches initSPP.
 
     tiles: every rank has just computed the targets of all tiles from its own film; only those of
@@ -155,11 +155,13 @@ def sync_adaptive(target, dist, world: int, mode: str, rank: int = 0):
     spp: sum the films so that every rank sees the complete film of the first initSPP samples,
     recompute the targets from it with SPP = the global count (identical input, identical targets on
     every rank), then put the rank's own partial film back so that the final reduction still counts
-    each sample once. Targets are in global sample indices either way."""
+    each sample once. Targets are in global sample indices either way.
+    wide_filter (Gaussian / Mitchell, whose splats reach into the neighbouring tiles, RTBase/Imaging.h:324-339): no
+    tile is complete on its owner, so the tile split sums the films like the sample split."""
     if world <= 1:
         return
     torch = importlib.import_module("torch")
-    if mode == "tiles":
+    if mode == "tiles" and not wide_filter:
         tiles = target.tiles()
         owner = torch.arange(tiles.numel(), device=tiles.device) % world
         mine = torch.where(owner == rank, tiles, torch.zeros_like(tiles))
@@ -179,11 +181,14 @@ def sync_adaptive(target, dist, world: int, mode: str, rank: int = 0):
 
 
 def render_sharded(target, settings, dist, rank: int, world: int, mode: str, reduce: bool = True):
-    """Render ``settings.total_spp`` GLOBAL samples per pixel across ``world`` ranks and (reduce)
+    """Starts from an empty film (``target.spp() == 0``).
+    Render ``settings.total_spp`` GLOBAL samples per pixel across ``world`` ranks and (reduce)
     leave the complete film, SPP = total_spp, on every rank. ``target`` must already carry
     ``shard_settings(settings, rank, world, mode)``. With adaptive sampling the ranks meet once,
     when the global count reaches initSPP (``sync_adaptive``); otherwise the only collective is
     the final film sum."""
+    if target.spp() != 0:
+        raise RuntimeError(f"render_sharded starts from an empty film: SPP is {target.spp()}, clear it first")
     total = int(settings.total_spp)
     adaptive = bool(settings.adaptive_sampling) and settings.algorithm == _pkg.AL_PATH_TRACE and settings.draw_mode == _pkg.DM_ALGORITHM
     init = int(settings.init_spp)
@@ -191,7 +196,7 @@ def render_sharded(target, settings, dist, rank: int, world: int, mode: str, red
     if world > 1 and adaptive and init < total:
         n_init = passes_for_rank(init, rank, world, mode)
         target.render(n_init)
-        sync_adaptive(target, dist, world, mode, rank)
+        sync_adaptive(target, dist, world, mode, rank, wide_filter=settings.filter != _pkg.FT_BOX)
         target.render(n_local - n_init)
     else:
         target.render(n_local)

@@ -32,6 +32,12 @@ def lib(pkg):
 
 
 @pytest.fixture(scope="session")
+def lib_tuning(pkg):
+    """The tuning build of the library (same sources, -DRTX_TUNING): reads the measurement switches such as RTX_FINE."""
+    return pkg.load_library(pkg.LIB_TUNING_PATH)
+
+
+@pytest.fixture(scope="session")
 def orc(pkg):
     pyoracle = importlib.import_module("oracle.pyoracle")
     return pyoracle.Oracle(pkg)

@@ -473,7 +473,7 @@ def test_rccl_collective_on_a_single_rank_communicator(pkg, lib, core, scenes):
 # ---- many passes in flight, every way the work is handed out -----------------------------------
 
 @pytest.mark.parametrize("fine", ["0", None], ids=["chunks_only", "default"])
-def test_passes_in_flight_equal_one_pass_per_call(pkg, lib, core, scenes, fine, monkeypatch):
+def test_passes_in_flight_equal_one_pass_per_call(pkg, lib, lib_tuning, core, scenes, fine, monkeypatch):
     """Full-size Cornell stand-in (1024x1024: every launch fills the grid, rays of a few steps each, so the waves
     ask for work all the time and meet at the end of every queue), 48 passes with three in flight against one pass
     per call. With the end of the queues handed out in chunks only (RTX_FINE=0) a wave whose lanes disagreed on
@@ -481,7 +481,7 @@ def test_passes_in_flight_equal_one_pass_per_call(pkg, lib, core, scenes, fine, 
     box-filter strays (a sample whose x + r rounds up into the next pixel is an atomic add on a pixel another
     sample owns: summation order)."""
     if fine is None: monkeypatch.delenv("RTX_FINE", raising=False)
-    else: monkeypatch.setenv("RTX_FINE", fine)
+    else: monkeypatch.setenv("RTX_FINE", fine); lib = lib_tuning        # only the tuning build reads the switch
     scene, cam = scenes.cornell_box("diffuse"), pkg.look_at(lib, width=1024, height=1024, **scenes.cornell_camera())
     st = pkg.make_settings(total_spp=48, max_bounces=5, use_mis=1, seed=77)
     films = []

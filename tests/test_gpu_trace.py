@@ -234,13 +234,13 @@ def test_ragged_batch_sizes_of_the_dynamic_fetch(pkg, lib, core, orc, scenes):
 
 
 @pytest.mark.parametrize("fine", [None, "0", "48", "4096"], ids=["default", "chunks_only", "48_per_wave", "everything_item_by_item"])
-def test_hand_out_boundaries(pkg, lib, orc, scenes, fine, monkeypatch):
+def test_hand_out_boundaries(pkg, lib, lib_tuning, orc, scenes, fine, monkeypatch):
     """The work hand-out changes its way with the size of a launch (5 120 waves on the device): below 32 rays per
     wave it is spread thin, the last 192 rays per wave (RTX_FINE overrides) go out item by item and whole chunks of
     64 before them. Sizes on both sides of every boundary, for several shares of the item-by-item part: each ray is
     traced exactly once (hits equal the oracle's, ray by ray)."""
     if fine is None: monkeypatch.delenv("RTX_FINE", raising=False)
-    else: monkeypatch.setenv("RTX_FINE", fine)
+    else: monkeypatch.setenv("RTX_FINE", fine); lib = lib_tuning        # only the tuning build reads the switch
     c = pkg.Core(0, lib)                      # the switch is read when a context is created
     sc = scenes.soup(5000, seed=37, size=0.05)
     c.upload_scene(sc)

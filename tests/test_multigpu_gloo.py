@@ -17,6 +17,9 @@ CASES = {
     # name: (settings keywords, width, height)
     "plain": (dict(total_spp=5, seed=17), 48, 40),
     "adaptive": (dict(total_spp=12, init_spp=4, adaptive_sampling=1, seed=19), 64, 48),
+    # Gaussian splats reach two pixels into the neighbouring tiles (RTBase/Imaging.h:324-339): under the tile split no
+    # tile is complete on its owner, so the adaptive meeting sums the films as the sample split does
+    "adaptive_gauss": (dict(total_spp=12, init_spp=4, adaptive_sampling=1, seed=19, filter=1), 64, 48),
     "radiosity": (dict(total_spp=4, seed=23, algorithm=2, num_threads=3, vpl_rays_per_tile=2), 40, 32),
     # light tracing (RTBase/Renderer.h:379-411): splats land anywhere on the film, so the ranks split the light paths
     # (by samples, or by the tiles whose pixels stand for the paths) and every film is a partial sum of the whole image
@@ -95,7 +98,7 @@ def _worker(rank, world, port, mode, case, out_dir):
 
 
 @pytest.mark.parametrize("mode,case", [("tiles", "plain"), ("spp", "plain"), ("tiles", "adaptive"), ("spp", "adaptive"),
-                                       ("tiles", "radiosity"), ("spp", "radiosity"), ("spp", "light"), ("tiles", "light")])
+                                       ("tiles", "radiosity"), ("spp", "radiosity"), ("spp", "light"), ("tiles", "light"), ("tiles", "adaptive_gauss")])
 def test_two_rank_partition_matches_single_rank(tmp_path, mode, case, pkg, orc, scenes):
     import torch.multiprocessing as mp
     port = 29500 + (os.getpid() * 7 + hash((mode, case))) % 2000
@@ -109,10 +112,10 @@ def test_two_rank_partition_matches_single_rank(tmp_path, mode, case, pkg, orc, 
     r = osc.renderer(pkg.make_settings(**kw), threads=4, counter_rng=True)
     r.render_passes(kw["total_spp"])
     want, _, want_tiles = r.film()
-    if case == "adaptive":
+    if case.startswith("adaptive"):
         assert np.array_equal(tiles[0], tiles[1])
         assert len(np.unique(want_tiles)) > 3 and want_tiles.min() < kw["total_spp"]      # tiles really are skipped
-        if mode == "tiles":
+        if mode == "tiles" and case == "adaptive":
             assert np.array_equal(tiles[0], want_tiles)
         else:
             # the summed film of the first initSPP samples differs from the sequential sum in the last bits
@@ -120,9 +123,9 @@ def test_two_rank_partition_matches_single_rank(tmp_path, mode, case, pkg, orc, 
     if case == "light":
         # the same splats in another summation order
         assert want.sum() > 0 and np.allclose(films[0], want, rtol=1e-5, atol=1e-6)
-    elif mode == "tiles":
+    elif mode == "tiles" and case != "adaptive_gauss":
         assert np.array_equal(films[0], want)
-    elif case == "adaptive":
+    elif case.startswith("adaptive"):
         same = np.repeat(np.repeat((tiles[0] == want_tiles).reshape((h + 15) // 16, (w + 15) // 16), 16, 0), 16, 1)[:h, :w]
         assert same.mean() > 0.8
         assert np.allclose(films[0] * same[..., None], want * same[..., None], rtol=1e-5, atol=1e-6)
