@@ -85,8 +85,14 @@ __device__ __forceinline__ bool packet_occluded(const DeviceScene& sc, PacketSta
             if (wave_stats) { wave_stats[0]++; wave_stats[1] += (uint32_t)__popcll(mask); }
             const uint32_t cr[4] = {cp[0], cp[1], cp[2], cp[3]};
             if (one_way) {
-                ConstFloat* nx = np + offx; ConstFloat* ny = np + offy; ConstFloat* nz = np + offz;
-                ConstFloat* fx = np + (offx ^ 12u); ConstFloat* fy = np + (offy ^ 20u); ConstFloat* fz = np + (offz ^ 28u);
+                ConstFloat* pnx = np + offx; ConstFloat* pny = np + offy; ConstFloat* pnz = np + offz;
+                ConstFloat* pfx = np + (offx ^ 12u); ConstFloat* pfy = np + (offy ^ 20u); ConstFloat* pfz = np + (offz ^ 28u);
+                const float nx[4] = {pnx[0], pnx[1], pnx[2], pnx[3]}, ny[4] = {pny[0], pny[1], pny[2], pny[3]}, nz[4] = {pnz[0], pnz[1], pnz[2], pnz[3]};
+                const float fx[4] = {pfx[0], pfx[1], pfx[2], pfx[3]}, fy[4] = {pfy[0], pfy[1], pfy[2], pfy[3]}, fz[4] = {pfz[0], pfz[1], pfz[2], pfz[3]};
+                // all seven loads of the node go out together (left alone, the compiler loads the planes of each slot
+                // behind the test of its child reference: four dependent round trips per node instead of one)
+                asm volatile("" :: "s"(nx[0]), "s"(nx[1]), "s"(nx[2]), "s"(nx[3]), "s"(ny[0]), "s"(ny[1]), "s"(ny[2]), "s"(ny[3]), "s"(nz[0]), "s"(nz[1]), "s"(nz[2]), "s"(nz[3]));
+                asm volatile("" :: "s"(fx[0]), "s"(fx[1]), "s"(fx[2]), "s"(fx[3]), "s"(fy[0]), "s"(fy[1]), "s"(fy[2]), "s"(fy[3]), "s"(fz[0]), "s"(fz[1]), "s"(fz[2]), "s"(fz[3]));
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     if (cr[c] == kEmptySlot) continue;          // (wave-uniform)

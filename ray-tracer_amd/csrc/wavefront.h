@@ -924,11 +924,18 @@ __global__ __launch_bounds__(kBlock) void k_ir_shade(WfPtrs w, DeviceScene sc, u
         sd.gNormal = sd.sNormal; sd.tu = sd.tv = 0.0f; sd.t = 0.0f;
         sd.frame.fromVector(sd.sNormal);
         C3 acc = first ? mkc(0, 0, 0) : ldc(w.L + 3 * slot);
-        for (uint32_t vl = 0; vl < nv; vl++) {
-            if (!vis[(size_t)vl * ng + g]) continue;
-            const float* v = w.vplc + 10 * (size_t)(v0 + vl);
-            V3 wi; const float gt = ir_geometry(sd.x, sd.sNormal, ld3(v), ld3(v + 3), wi);
-            acc = acc + bsdf_evaluate(sc, sd, wi) * ldc(v + 6) * gt;
+        // eight result bytes at a time, so that their loads are in flight together (one dependent load per VPL otherwise)
+        for (uint32_t v8 = 0; v8 < nv; v8 += 8u) {
+            uint8_t flag[8];
+#pragma unroll
+            for (uint32_t q = 0; q < 8u; q++) flag[q] = v8 + q < nv ? vis[(size_t)(v8 + q) * ng + g] : (uint8_t)0;
+#pragma unroll
+            for (uint32_t q = 0; q < 8u; q++) {
+                if (!flag[q]) continue;
+                const float* v = w.vplc + 10 * (size_t)(v0 + v8 + q);
+                V3 wi; const float gt = ir_geometry(sd.x, sd.sNormal, ld3(v), ld3(v + 3), wi);
+                acc = acc + bsdf_evaluate(sc, sd, wi) * ldc(v + 6) * gt;
+            }
         }
         if (last) acc = acc / (float)total;
         st3(w.L + 3 * slot, acc);
