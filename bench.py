@@ -39,7 +39,9 @@ def main():
     ap.add_argument("--no-pathtrace", action="store_true")
     ap.add_argument("--no-big", action="store_true", help="skip the 10 M-triangle 4K closest-hit measurement")
     ap.add_argument("--only", default="", choices=["", "headline", "extras", "pathtrace"], help="profiling: run the headline leg plus only this part")
-    ap.add_argument("--pt-spp", type=int, default=64, help="passes of the path-trace side measurement")
+    ap.add_argument("--pt-spp", type=int, default=64, help="passes of the path-trace side measurement PER RANK (weak scaling: N ranks render N x this)")
+    ap.add_argument("--pt-total-spp", type=int, default=0, help="path-trace leg with this many passes IN TOTAL, split over the ranks (strong scaling); overrides --pt-spp")
+    ap.add_argument("--no-radiosity", action="store_true", help="skip the instant-radiosity side measurement")
     ap.add_argument("--variants", default="", help="A/B: comma list of RTX_VARIANT values, interleaved rounds in one process")
     ap.add_argument("--ab-scene", default="soup", choices=["soup", "mixed"])
     ap.add_argument("--ab-repeat", type=int, default=1, help="A/B: trace the ray set this many times in one launch (tail measurement)")
@@ -192,22 +194,29 @@ def main():
 
 # ---- ceilings and committed profile summaries --------------------------------------------------------
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak
-VALU_PEAK_NO_FMA_TFLOPS = 78.65  # 157.3 TFLOP/s fp32 vector peak counts a multiply-add as two: plain IEEE multiplies and adds (no contraction,
-#                                  which bit parity with the reference forbids) can reach half of it
+VALU_PEAK_SPEC_TFLOPS = 157.3    # fp32 vector peak of the data sheet: every lane a fused multiply-add (two flops) per clock
+VALU_PEAK_NO_FMA_TFLOPS = 78.65  # the same issue rate with plain IEEE multiplies and adds, one flop each: contraction into multiply-adds
+#                                  changes the rounding, and hit ids / distances must match the reference's plain evaluation bit for bit
 SLAB_FLOPS, TRI_FLOPS = 25, 55   # per ray-box test (RTBase/Geometry.h:216-227) and per Moller-Trumbore test (:99-120)
 NODE_LOADS, GROUP_LOADS = 7, 9   # 16-byte loads per lane: one 4-wide node (112 of its 128 bytes), one leaf fetch (four 36-byte triangle records)
 
 
 def load_profiles():
     """profiles/r02_ceilings.json: the measured ceiling of per-lane 16-byte gathers (tools/gather_probe.hip);
-    profiles/r02_pmc.json: hardware-counter summaries of the same commands (tools/pmc_collect.sh). Both are
-    committed measurements; a missing file only removes the fields that need it."""
+    profiles/r03_pmc.json (or the one of the round before): hardware-counter summaries of the same commands
+    (tools/pmc_collect.sh). Both are committed measurements, taken in a profiler run of their own: the roofline blocks
+    say which file the counter fields come from, how long the kernel took in THAT run (`counters_kernel_ms`) and flag
+    them `counters_stale` when the kernel timed live differs from it by more than 10 %. A missing file only removes
+    the fields that need it."""
     out = {}
-    for key, name in (("ceilings", "r02_ceilings.json"), ("pmc", "r02_pmc.json")):
-        try:
-            out[key] = json.load(open(os.path.join(ROOT, "profiles", name)))
-        except Exception:
-            out[key] = {}
+    for key, names in (("ceilings", ("r02_ceilings.json",)), ("pmc", ("r03_pmc.json", "r02_pmc.json"))):
+        out[key] = {}
+        for name in names:
+            try:
+                out[key] = json.load(open(os.path.join(ROOT, "profiles", name)))
+                break
+            except Exception:
+                pass
     return out
 
 
@@ -249,17 +258,27 @@ def roofline(n, nodes, tris, groups, kernel_ms, prof, pmc_key):
     l1_ceiling = ceil.get("l1_lookups_per_clk_per_cu")
     r = {"bound": "valu", "achieved": round(tflops, 2), "peak": VALU_PEAK_NO_FMA_TFLOPS, "unit": "TFLOP/s",
          "frac": round(tflops / VALU_PEAK_NO_FMA_TFLOPS, 4), "traffic": traffic,
+         "peak_spec": VALU_PEAK_SPEC_TFLOPS, "frac_vs_spec_peak": round(tflops / VALU_PEAK_SPEC_TFLOPS, 4),
+         "peak_note": "peak = fp32 vector rate for un-fused multiplies and adds (bit parity with the reference forbids multiply-add contraction); peak_spec = the data-sheet rate, which counts a fused multiply-add as two flops",
          "kernel": "k_closest", "kernel_ms": round(kernel_ms, 4),
          "flops_per_ray": round(flops / n, 1), "nodes_per_ray": round(nodes / n, 2), "tris_per_ray": round(tris / n, 2),
-         "leaf_fetches_per_ray": round(groups / n, 2),
-         "valu_busy": pmc.get("valu_busy"), "live_lane_frac": pmc.get("live_lane_frac"),
-         "useful_share_of_lane_ops": round(flops / n / (lane_ops / rays_pmc), 3) if lane_ops and rays_pmc else None,
-         "l1": {"lookups_per_clk_per_cu": l1, "ceiling": l1_ceiling, "frac": round(l1 / l1_ceiling, 3) if l1 and l1_ceiling else None,
-                "ta_busy": pmc.get("ta_busy"), "lane_loads_16B_gbs": round(16.0 * (NODE_LOADS * nodes + GROUP_LOADS * groups) / s / 1e9, 1)},
-         "hbm": {"bytes_per_launch": traffic, "gbs": round(traffic / s / 1e9, 1) if traffic else None, "peak": HBM_PEAK_GBS,
-                 "frac": round(traffic / s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None, "l2_hit": pmc.get("l2_hit"),
-                 "requested_at_cache_level_gbs": round((n * (RAY_BYTES + HIT_BYTES) + nodes * NODE_BYTES + tris * TRI_BYTES) / s / 1e9, 1)},
-         "counters_from": pmc.get("source")}
+         "leaf_fetches_per_ray": round(groups / n, 2)}
+    lanes = 16.0 * (NODE_LOADS * nodes + GROUP_LOADS * groups) / s / 1e9
+    requested = (n * (RAY_BYTES + HIT_BYTES) + nodes * NODE_BYTES + tris * TRI_BYTES) / s / 1e9
+    if pmc:
+        cms = pmc.get("duration_ns", 0) / 1e6
+        r.update({"valu_busy": pmc.get("valu_busy"), "live_lane_frac": pmc.get("live_lane_frac"),
+                  "useful_share_of_lane_ops": round(flops / n / (lane_ops / rays_pmc), 3) if lane_ops and rays_pmc else None,
+                  "l1": {"lookups_per_clk_per_cu": l1, "ceiling": l1_ceiling, "frac": round(l1 / l1_ceiling, 3) if l1 and l1_ceiling else None,
+                         "ta_busy": pmc.get("ta_busy"), "lane_loads_16B_gbs": round(lanes, 1)},
+                  "hbm": {"bytes_per_launch": traffic, "gbs": round(traffic / s / 1e9, 1) if traffic else None, "peak": HBM_PEAK_GBS,
+                          "frac": round(traffic / s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None, "l2_hit": pmc.get("l2_hit"),
+                          "requested_at_cache_level_gbs": round(requested, 1)},
+                  "counters_from": pmc.get("source"), "counters_kernel_ms": round(cms, 4) if cms else None,
+                  "counters_stale": bool(cms) and abs(cms - kernel_ms) > 0.1 * kernel_ms})
+    else:
+        # no counter run of this launch is committed: only what this run measures
+        r.update({"l1": {"lane_loads_16B_gbs": round(lanes, 1)}, "hbm": {"requested_at_cache_level_gbs": round(requested, 1)}})
     return r
 
 
@@ -293,6 +312,9 @@ def spawn_ranks(n: int) -> int:
         port = sk.getsockname()[1]
     procs = []
     for r in range(n):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver of these machines supports dmabuf IPC only, and RCCL's exchange of
+        # device buffers between the rank processes fails without it (hipIpcGetMemHandle: invalid argument). The image
+        # exports it already; it is repeated here so that a launch from a scrubbed environment behaves the same.
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
@@ -362,39 +384,77 @@ def ab_visible(pkg, lib, scene, cam, args, seg, torch, local_rank):
                           "msegments_per_s_median": round(n / t[len(t) // 2] / 1e3, 1), "visible_share": round(float(ref.float().mean()), 3)}))
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_has(flag):
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                return flag in line.split()
+    except OSError:
+        pass
+    return False
+
+
+ORACLE_FLAGS = {"O2": "g++ -std=c++17 -O2 -ffp-contract=off -fno-fast-math -pthread", "O3": "g++ -std=c++17 -O3 -march=x86-64-v3 -ffp-contract=off -fno-fast-math -pthread"}
+
+
 def cpu_baseline(pkg, scene, cam, args):
-    """The CPU oracle (a port of the reference's BVH traversal, RTBase/Geometry.h:506-566)
-    on this box's host cores, over the rays of the same batch, traced three times (~15-20 s of CPU work
-    summed over the threads)."""
+    """The CPU oracle (a port of the reference's BVH traversal, RTBase/Geometry.h:506-566, and of renderMT,
+    RTBase/Renderer.h:753-782) on this box's host cores, over the rays of the same batch, traced three times
+    (~15-20 s of CPU work summed over the threads). Threads: every hardware thread this job may use, which is what
+    the reference does (numThreads = min(settings.numThreads, numProcs), RTBase/Renderer.h:92) - on a GPU box that is
+    the CPU share of one GPU (OMP_NUM_THREADS there), not the whole machine's count. Two builds of the same source: -O2
+    (the build the parity tests check, the value of record) and -O3 for AVX2 (the reference's Release configuration
+    targets AVX2), reported beside it."""
     pyoracle = importlib.import_module("oracle.pyoracle")
-    orc = pyoracle.Oracle(pkg)
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 8, 16)
-    osc = orc.scene(scene)
-    osc.set_camera(cam)
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 8)
     ys, xs = np.mgrid[0:args.height, 0:args.width]
     xy = np.stack([xs.ravel() + 0.5, ys.ravel() + 0.5], 1).astype(np.float32)
-    rays = osc.generate_rays(xy)
-    reps = 3
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        osc.trace_closest(rays, threads=threads)
-    dt = time.perf_counter() - t0
-    osc.close()
-    out = {"value": round(reps * len(rays) / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-           "sample": f"the whole batch ({len(rays)} rays) {reps} times, {threads} threads, BVH build excluded"}
-    if not args.no_pathtrace:
-        # the port of renderMT (RTBase/Renderer.h:753-782, per-thread MT19937 streams) on the path-trace side scene
-        scenes = importlib.import_module("ray-tracer_amd.scenes")
-        mixed = scenes.mixed_scene(128)
-        osc = orc.scene(mixed)
-        osc.set_camera(pkg.look_at(pkg.load_library(), width=args.width, height=args.height, **scenes.mixed_camera()))
-        ren = osc.renderer(pkg.make_settings(total_spp=8, max_bounces=5, use_mis=1), threads=threads, counter_rng=False)
+    builds = [("O2", pyoracle.LIB)]
+    if os.path.exists(pyoracle.LIB_O3) and cpu_has("avx2") and cpu_has("fma") and cpu_has("bmi2"):
+        builds.append(("O3", pyoracle.LIB_O3))
+    res = {}
+    for tag, path in builds:
+        orc = pyoracle.Oracle(pkg, path)
+        osc = orc.scene(scene)
+        osc.set_camera(cam)
+        rays = osc.generate_rays(xy)
+        reps = 3
         t0 = time.perf_counter()
-        ren.render_passes(8)
+        for _ in range(reps):
+            osc.trace_closest(rays, threads=threads)
         dt = time.perf_counter() - t0
-        ren.close(); osc.close()
-        out["pathtrace_spp_per_s"] = round(8 / dt, 4)
-        out["pathtrace_sample"] = f"8 passes of the {args.width}x{args.height} mixed-material scene, {threads} threads"
+        osc.close()
+        r = {"value": round(reps * len(rays) / dt / 1e6, 3), "unit": "Mrays/s", "compiler_flags": ORACLE_FLAGS[tag]}
+        if not args.no_pathtrace:
+            # the port of renderMT (per-thread MT19937 streams) on the path-trace side scene
+            scenes = importlib.import_module("ray-tracer_amd.scenes")
+            mixed = scenes.mixed_scene(128)
+            osc = orc.scene(mixed)
+            osc.set_camera(orc.look_at(scenes.mixed_camera()["frm"], scenes.mixed_camera()["to"], scenes.mixed_camera()["up"], scenes.mixed_camera()["fov"], args.width, args.height))
+            passes = 4
+            ren = osc.renderer(pkg.make_settings(total_spp=passes, max_bounces=5, use_mis=1), threads=threads, counter_rng=False)
+            t0 = time.perf_counter()
+            ren.render_passes(passes)
+            dt = time.perf_counter() - t0
+            ren.close(); osc.close()
+            r["pathtrace_spp_per_s"] = round(passes / dt, 4)
+            r["pathtrace_sample"] = f"{passes} passes of the {args.width}x{args.height} mixed-material scene"
+        res[tag] = r
+    out = dict(res["O2"])
+    out.update({"cores": threads, "kind": "port", "cpu_model": cpu_model(), "hardware_threads_of_the_machine": os.cpu_count(),
+                "sample": f"the whole batch ({args.width * args.height} rays) 3 times, {threads} threads, BVH build excluded"})
+    if "O3" in res:
+        out["o3_avx2_build"] = res["O3"]
     return out
 
 
@@ -418,7 +478,10 @@ def pathtrace_side(pkg, scenes, lib, core, torch, dist, world, rank, dev, args, 
         core.upload_scene(scene)
         cam = pkg.look_at(lib, width=args.width, height=args.height, **scenes.mixed_camera())
         core.set_camera(cam)
-        base = pkg.make_settings(total_spp=args.pt_spp * world, seed=1)
+        # weak scaling by default (every rank adds --pt-spp passes of its own); --pt-total-spp fixes the total instead (strong)
+        total = args.pt_total_spp if args.pt_total_spp else args.pt_spp * world
+        scaling = "strong" if args.pt_total_spp else "weak"
+        base = pkg.make_settings(total_spp=total, seed=1)
         core.set_settings(mg.shard_settings(base, rank, world, "spp"))
         target = mg.CoreTarget(core, torch)
         core.clear()
@@ -436,14 +499,47 @@ def pathtrace_side(pkg, scenes, lib, core, torch, dist, world, rank, dev, args, 
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             all_reduce(t, dist.ReduceOp.MAX)
             dt = float(t.item())
-        out = {"pathtrace_spp_per_s": round(args.pt_spp * world / dt, 3),
+        out = {"pathtrace_spp_per_s": round(total / dt, 3),
                "pathtrace_config": {"workload": f"configs[2]: mixed Diffuse/Mirror/Glass/Conductor/Plastic scene ({scene.n_triangles} triangles) + 1024x512 env-map MIS, {args.width}x{args.height}, maxBounces 5",
-                                    "spp_timed": args.pt_spp * world, "parallelism": f"spp split x{world} + film all-reduce" if world > 1 else "1 GPU"}}
+                                    "spp_timed": total, "scaling": scaling,
+                                    "parallelism": f"spp split x{world} + one film all-reduce ({core.film_device()[1] * 4} bytes per rank) at the end, inside the timed region" if world > 1 else "1 GPU"}}
         if rank == 0 and world == 1:
-            out["pathtrace_roofline"] = pathtrace_roofline(core, dt / args.pt_spp, prof)
+            out["pathtrace_roofline"] = pathtrace_roofline(core, dt / total, prof)
+            if not args.no_radiosity:
+                out["instant_radiosity"] = radiosity_side(pkg, core, args)
         return out
     except pkg.RtxError as e:
         return {"pathtrace_spp_per_s": None, "pathtrace_error": str(e)}
+
+
+def radiosity_side(pkg, core, args):
+    """Instant radiosity on the scene the core holds (the mixed-material scene at the path-trace leg's resolution), 128
+    light paths per pass (numThreads 8 x vplRaysPerTile 16, RTBase/Renderer.h:174,283): every gathering pixel connects to
+    every valid VPL of the pass (RTBase/Renderer.h:210-245). The work figures come from two instrumented passes; the
+    fraction prices the slab and triangle tests of all rays of a pass (camera rays, light paths, gather segments) at the
+    un-fused fp32 vector peak against the measured time of a pass."""
+    core.set_settings(pkg.make_settings(algorithm=pkg.AL_INSTANT_RADIOSITY, total_spp=1 << 20, max_bounces=5, num_threads=8, vpl_rays_per_tile=16, seed=1))
+    core.clear(); core.render_passes(3); core.clear()
+    passes = 24
+    t0 = time.perf_counter()
+    core.render_passes(passes)
+    dt = (time.perf_counter() - t0) / passes
+    core.clear()
+    t0 = time.perf_counter()
+    for _ in range(8):
+        core.render_passes(1)
+    single = (time.perf_counter() - t0) / 8
+    core.clear()
+    w = core.count_render_work(2)
+    rays = max(1, w["closest_rays"] + w["shadow_rays"])
+    flops = (4 * SLAB_FLOPS * w["nodes"] + TRI_FLOPS * w["tris"]) / 2
+    return {"passes_per_s": round(1.0 / dt, 1), "ms_per_pass": round(dt * 1e3, 4), "ms_per_pass_one_in_flight": round(single * 1e3, 4),
+            "light_paths_per_pass": 128, "valid_vpls_per_pass": w["vpls"] / 2, "gather_segments_per_pass": w["gather_segments"] / 2,
+            "gather_gsegments_per_s": round(w["gather_segments"] / 2 / dt / 1e9, 2),
+            "nodes_per_ray": round(w["nodes"] / rays, 2), "tris_per_ray": round(w["tris"] / rays, 2),
+            "traversal_flops_per_pass": int(flops), "useful_tflops": round(flops / dt / 1e12, 2), "peak": VALU_PEAK_NO_FMA_TFLOPS,
+            "frac": round(flops / dt / 1e12 / VALU_PEAK_NO_FMA_TFLOPS, 4), "kernel": "k_ir_trace_packet",
+            "resolution": [args.width, args.height]}
 
 
 def pathtrace_roofline(core, s_per_pass, prof):

@@ -13,6 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(_HERE, "liboracle.so")
+LIB_O3 = os.path.join(_HERE, "liboracle_o3.so")
 REF_LIB = os.path.join(_HERE, "_ref", "libref_core.so")
 
 _f = C.POINTER(C.c_float)
@@ -23,12 +24,13 @@ def _p(a):
 
 
 class Oracle:
-    def __init__(self, rtx_pkg):
-        """rtx_pkg: the product package module (for the shared ctypes struct definitions)."""
-        if not os.path.exists(LIB):
-            raise RuntimeError(f"{LIB} missing: run make -C oracle")
+    def __init__(self, rtx_pkg, lib_path: str = LIB):
+        """rtx_pkg: the product package module (for the shared ctypes struct definitions). lib_path: LIB, or LIB_O3 for
+        the -O3 / AVX2 build that bench.py times beside it (same source, same results)."""
+        if not os.path.exists(lib_path):
+            raise RuntimeError(f"{lib_path} missing: run make -C oracle")
         self.pkg = rtx_pkg
-        lib = self.lib = C.CDLL(LIB)
+        lib = self.lib = C.CDLL(lib_path)
         vp = C.c_void_p
         lib.orc_scene_create.restype = vp
         lib.orc_scene_create.argtypes = [C.POINTER(rtx_pkg.SceneDesc)]

@@ -56,6 +56,8 @@ struct rtx_ctx {
     int variant = 1;               // traversal schedule (RTX_VARIANT): 1 = default, 0 = static baseline, >= 2 = schedules under test
     int resident_blocks = rtx::kMaxGridBlocks;   // traversal workgroups the device holds at once
     int resident_packet_blocks = rtx::kMaxGridBlocks;   // the same for the packet kernels (traverse_packet.h)
+    int primary_packet = 0;        // (tuning build, RTX_PRIMARY_PACKET=1) camera rays of a render pass: packets of 64 (k_closest_packet), the rest per lane
+    int query_packet = 0;          // (tuning build, RTX_QUERY_PACKET=1) rtx_trace_closest_device: the same for coherent runs of the caller's rays
     int ir_packet = 1;             // instant-radiosity gather: one traversal per wave (RTX_IR_PACKET=0: one per lane)
     int rays_per_block = 16;       // grid of a ray-query launch too small to fill the device: one workgroup per this many rays
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -73,6 +75,7 @@ struct rtx_ctx {
     uint32_t spill_entries = 0;    // entries per lane in b_spill
     uint32_t stack_need = 0;       // traversal-stack entries a ray of the current scene can need at most
     void* na_scratch = nullptr;    // this device's copy of the static scratch of the no-allocation entry point
+    rtx::DevBuf b_rest;            // ray queries: items the packet kernel left to the per-lane kernel
     rtx::DevBuf b_io_a, b_io_b;    // staging for the host-pointer entry points
     rtx::PinBuf pin_in, pin_out;
     hipEvent_t io_kernel_done[2] = {nullptr, nullptr};   // host-buffer ray queries: the kernel of a chunk has finished

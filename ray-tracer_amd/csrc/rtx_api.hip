@@ -185,8 +185,13 @@ static int create_resources(rtx_ctx* c, int device)
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_closest<false>, kBlock, 0));
         c->resident_blocks = std::max(1, std::min(kMaxGridBlocks, per_cu * prop.multiProcessorCount));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_ir_trace_packet, kBlock, 0));
+#ifdef RTX_TUNING
+        { int pc = 0; HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_closest_packet, kBlock, 0)); per_cu = std::min(per_cu, pc); }
+#endif
         c->resident_packet_blocks = std::max(1, std::min(kMaxGridBlocks, per_cu * prop.multiProcessorCount));
         if (const char* v = tuning_env("RTX_IR_PACKET")) c->ir_packet = atoi(v);
+        if (const char* v = tuning_env("RTX_PRIMARY_PACKET")) c->primary_packet = atoi(v);
+        if (const char* v = tuning_env("RTX_QUERY_PACKET")) c->query_packet = atoi(v);
         if (const char* g = tuning_env("RTX_GRID")) c->resident_blocks = std::max(1, std::min(kMaxGridBlocks, atoi(g)));   // tuning override
         if (tuning_env("RTX_DEBUG_COUNTERS")) fprintf(stderr, "[rtx] %d CUs x %d resident traversal workgroups\n", prop.multiProcessorCount, per_cu);
     }
@@ -206,7 +211,7 @@ static int create_resources(rtx_ctx* c, int device)
     if (const char* v = tuning_env("RTX_MERGE")) c->merge_shadow = atoi(v) != 0;
     if (const char* v = tuning_env("RTX_RAYS_PER_BLOCK")) c->rays_per_block = std::max(1, std::min(kBlock, atoi(v)));
     if (const char* v = tuning_env("RTX_PIPELINE")) c->pipeline = std::max(1, std::min(kPipeline, atoi(v)));
-    HIP_TRY(c->b_counters.ensure(4 * (1 + 2) * kWorkSlotWords));   // instrumentation counters, then the work-counter slots of the closest-hit and visibility launches
+    HIP_TRY(c->b_counters.ensure(4 * 5 * kWorkSlotWords));   // instrumentation counters, then the work-counter slots of the closest-hit, visibility and packet launches (+ the length of the packet kernel's rest queue)
     // RayTracer's defaults, RTBase/Settings.h:40-61
     rtx_settings& s = c->settings;
     s.algorithm = RTX_AL_PATH_TRACE; s.draw_mode = RTX_DM_ALGORITHM; s.filter = RTX_FT_BOX;
@@ -529,9 +534,24 @@ int rtx_trace_closest_device(rtx_ctx* c, const rtx_ray* rays, size_t n, rtx_hit*
 #endif
     {
         uint32_t* wc = c->b_counters.as<uint32_t>() + kWorkSlotWords;
+        const uint32_t* queue = nullptr; const uint32_t* n_dev = nullptr;
+#ifdef RTX_TUNING
+        if (c->query_packet && c->stack_need <= (uint32_t)kPacketStack && n >= 4096) {
+            // coherent runs of 64 rays (camera rays in pixel-block order) are walked as packets, one traversal per wave;
+            // what does not fit goes to the per-lane kernel below through a queue
+            HIP_TRY(c->b_rest.ensure(n * sizeof(uint32_t)));
+            uint32_t* pw = c->b_counters.as<uint32_t>() + 3 * kWorkSlotWords;
+            uint32_t* rest_count = pw + kWorkSlotWords;
+            HIP_TRY(hipMemsetAsync(pw, 0, (kWorkSlotWords + 1) * 4, c->stream));
+            const size_t packets = (n + 63) / 64;
+            hipLaunchKernelGGL(k_closest_packet, dim3((unsigned)std::min<size_t>((packets + 3) / 4, (size_t)c->resident_packet_blocks)), dim3(kBlock), 0, c->stream, c->dscene, rays,
+                               (const uint32_t*)nullptr, (uint32_t)n, (const uint32_t*)nullptr, hits, c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), pw, c->b_rest.as<uint32_t>(), rest_count);
+            queue = c->b_rest.as<uint32_t>(); n_dev = rest_count;
+        }
+#endif
         HIP_TRY(hipMemsetAsync(wc, 0, kWorkSlotWords * 4, c->stream));
-        hipLaunchKernelGGL(k_closest<false>, dim3(dyn_grid_for(c, n)), dim3(kBlock), 0, c->stream, c->dscene, rays, (const uint32_t*)nullptr,
-                           (uint32_t)n, (const uint32_t*)nullptr, hits, c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), wc,
+        hipLaunchKernelGGL(k_closest<false>, dim3(dyn_grid_for(c, n)), dim3(kBlock), 0, c->stream, c->dscene, rays, queue,
+                           (uint32_t)n, n_dev, hits, c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), wc,
                            (unsigned long long*)nullptr);
     }
     HIP_TRY(hipGetLastError());

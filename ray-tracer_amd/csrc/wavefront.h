@@ -1083,6 +1083,20 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         else hipLaunchKernelGGL(k_closest<false>, gridT, blk, 0, s, dscene, (const rtx_ray*)w.ray, queue, 0u, (const uint32_t*)(w.cnt + counter * kQueueStride), w.hit, spill, sstride,
                            w.cnt + kClosestWorkBase + counter * kWorkSlotWords, (unsigned long long*)nullptr);
     };
+    // camera rays (queue 0 of a pass, in pixel-block order): packets of 64 first, what does not fit a packet per lane.
+    // The rest queue is w.qb (free until the first shade kernel of the pass writes it), its length queue word 95.
+    auto closest_primary = [&]() {
+#ifndef RTX_TUNING
+        closest(w.qa, 0);
+#else
+        if (cw || !c->primary_packet || c->stack_need > (uint32_t)kPacketStack) { closest(w.qa, 0); return; }
+        uint32_t* rest_count = w.cnt + 95 * kQueueStride;
+        hipLaunchKernelGGL(k_closest_packet, dim3(std::min<uint32_t>((w.P / 64 + 3) / 4, (uint32_t)c->resident_packet_blocks)), blk, 0, s, dscene, (const rtx_ray*)w.ray, (const uint32_t*)w.qa, 0u,
+                           (const uint32_t*)w.cnt, w.hit, spill, sstride, w.cnt + kShadowWorkBase + 94 * kWorkSlotWords, w.qb, rest_count);
+        hipLaunchKernelGGL(k_closest<false>, gridT, blk, 0, s, dscene, (const rtx_ray*)w.ray, (const uint32_t*)w.qb, 0u, (const uint32_t*)rest_count, w.hit, spill, sstride,
+                           w.cnt + kClosestWorkBase, (unsigned long long*)nullptr);
+#endif
+    };
     auto shadow = [&](hipStream_t on, uint32_t counter_index, uint32_t work_index, uint2* stacks) {
         if (cw) hipLaunchKernelGGL(k_shadow_accumulate<true>, gridT, blk, 0, on, w, dscene, counter_index, work_index, stacks, sstride, ctr);
         else hipLaunchKernelGGL(k_shadow_accumulate<false>, gridT, blk, 0, on, w, dscene, counter_index, work_index, stacks, sstride, (unsigned long long*)nullptr);
@@ -1093,7 +1107,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         // RTBase/Renderer.h:699-720
         hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, w, pp);
         hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
-        closest(w.qa, 0);
+        closest_primary();
         hipLaunchKernelGGL(k_dm_shade, gridQ, blk, 0, s, w, dscene, pp);
         shadow(s, (uint32_t)kShadowCounterBase, (uint32_t)kShadowWorkBase, spill);
         if (film_wait && hipStreamWaitEvent(s, film_wait, 0) != hipSuccess) return RTX_ERR_HIP;
@@ -1108,7 +1122,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
             // closest hits of depth d, shade(d); the shadow rays of the last depth go alone
             for (uint32_t d = 0; d <= st.max_bounces; d++) {
                 pp.depth = d;
-                if (d == 0) closest(qin, 0);
+                if (d == 0) closest_primary();
                 else if (cw) hipLaunchKernelGGL(k_pt_trace_mixed<true>, gridT, blk, 0, s, w, dscene, d, (const uint32_t*)qin, (uint32_t)(kClosestWorkBase + d * kWorkSlotWords), spill, sstride, ctr);
                 else hipLaunchKernelGGL(k_pt_trace_mixed<false>, gridT, blk, 0, s, w, dscene, d, (const uint32_t*)qin, (uint32_t)(kClosestWorkBase + d * kWorkSlotWords), spill, sstride,
                                         (unsigned long long*)nullptr);
@@ -1197,7 +1211,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         if (hipMemsetAsync(w.cnt, 0, kCounterWords * 4, s) != hipSuccess) return RTX_ERR_HIP;
         hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, w, pp);
         hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
-        closest(w.qa, 0);
+        closest_primary();
         hipLaunchKernelGGL(k_ir_prepare, gridQ, blk, 0, s, w, dscene, pp);
         for (uint32_t bi = 0; bi < std::max(batches, 1u); bi++) {
             const uint32_t v0 = bi * vb, work = (uint32_t)(kShadowWorkBase + bi * kWorkSlotWords);

@@ -28,3 +28,15 @@ def test_roofline_block_from_committed_profiles():
     product = r["valu_busy"] * r["live_lane_frac"] * r["useful_share_of_lane_ops"] * 0.5
     assert abs(product - r["frac"]) < 0.1 * r["frac"], (product, r["frac"])
     assert r["traffic"] == head["hbm_bytes_per_launch"]
+    # both peaks, and the check that the counters belong to the timing
+    assert abs(r["frac_vs_spec_peak"] - r["achieved"] / r["peak_spec"]) < 2e-3 and r["peak_spec"] == 2 * r["peak"]
+    assert r["counters_stale"] is False and abs(r["counters_kernel_ms"] - kernel_ms) < 1e-3
+    stale = bench.roofline(n, nodes, tris, groups, 0.8 * kernel_ms, prof, "headline")
+    assert stale["counters_stale"] is True
+    # a launch with no committed counter run carries no counter fields at all (and no nulls but `traffic`)
+    bare = bench.roofline(n, nodes, tris, groups, kernel_ms, prof, None)
+    assert bare["traffic"] is None and "valu_busy" not in bare and "counters_from" not in bare
+
+    def nulls(o):
+        return [k for k, v in o.items() if v is None] + [x for v in o.values() if isinstance(v, dict) for x in nulls(v)]
+    assert nulls(bare) == ["traffic"]

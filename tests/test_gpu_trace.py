@@ -278,3 +278,25 @@ def test_randomised_soups_closest_and_visible(pkg, lib, core, orc, scenes, seed,
     assert np.array_equal(core.trace_visible(seg), vis)
     assert np.array_equal(core.trace_visible(seg[:333]), vis[:333])
     osc.close()
+
+
+def test_closest_packets_of_the_tuning_build(pkg, lib_tuning, orc, scenes, monkeypatch):
+    """The tuning build can walk coherent runs of 64 rays as one packet per wave (k_closest_packet; measured slower
+    than the per-lane kernel at 1080p, so the shipped library does not). Camera rays in pixel-block order mixed with
+    incoherent and axis-parallel rays (which the packet kernel hands on to the per-lane kernel): hit records equal
+    the oracle's bit for bit."""
+    monkeypatch.setenv("RTX_QUERY_PACKET", "1")
+    c = pkg.Core(0, lib_tuning)
+    for sc, cam_kw in ((scenes.soup(60_000, seed=5), dict(frm=(0, 0, 3.5), to=(0, 0, 0), up=(0, 1, 0), fov=45.0)), (scenes.mixed_scene(32, (128, 64)), scenes.mixed_camera())):
+        c.upload_scene(sc)
+        osc = orc.scene(sc)
+        cam = pkg.look_at(lib_tuning, width=320, height=200, **cam_kw)
+        osc.set_camera(cam)
+        ys, xs = np.mgrid[0:200, 0:320]
+        # 8x8 pixel blocks, row-major inside a block: 64 consecutive rays are one block
+        order = np.argsort(((ys // 8) * 40 + xs // 8).ravel() * 64 + ((ys % 8) * 8 + xs % 8).ravel(), kind="stable")
+        prim = osc.generate_rays(np.stack([xs.ravel() + 0.5, ys.ravel() + 0.5], 1)[order])
+        rays = np.concatenate([prim, _rand_rays(pkg, 30_000, 3), prim[:6400], _axis_rays(pkg, 3_000, 4)])
+        _assert_hits_equal(c.trace_closest(rays), osc.trace_closest(rays, threads=8))
+        osc.close()
+    c.close()

@@ -77,9 +77,12 @@ def main():
           pkg.make_settings(total_spp=256, init_spp=10, adaptive_sampling=1, max_bounces=5), extra=tile_stats)
     timed("mixed_light_trace", mixed, scenes.mixed_camera(), 1920, 1080, 16 if q else 64,
           pkg.make_settings(algorithm=pkg.AL_LIGHT_TRACE, total_spp=64, max_bounces=5))
-    # 22 light paths x up to 6 vertices: ~128 VPLs per pass
-    timed("mixed_instant_radiosity", mixed, scenes.mixed_camera(), 1920, 1080, 2 if q else 8,
-          pkg.make_settings(algorithm=pkg.AL_INSTANT_RADIOSITY, total_spp=8, max_bounces=5, vpl_rays_per_tile=1, num_threads=22), warm=1)
+    # 128 light paths per pass (8 threads x 16 paths, RTBase/Renderer.h:174,283); the row records the valid VPLs they leave
+    def vpl_stats(film, spp, tiles):
+        w = core.count_render_work(2)
+        return {"light_paths_per_pass": 128, "valid_vpls_per_pass": w["vpls"] / 2, "gather_segments_per_pass": w["gather_segments"] / 2}
+    timed("mixed_instant_radiosity", mixed, scenes.mixed_camera(), 1920, 1080, 4 if q else 24,
+          pkg.make_settings(algorithm=pkg.AL_INSTANT_RADIOSITY, total_spp=1 << 20, max_bounces=5, vpl_rays_per_tile=16, num_threads=8), warm=2, extra=vpl_stats)
 
     # configs[3]: ~10 M triangles at 4K; whole film, then the tiles of rank 0 of 2
     terr = scenes.terrain(707 if q else 2236)
