@@ -21,6 +21,7 @@ LIB_TUNING_PATH = os.path.join(_HERE, "librtx_tuning.so")
 AL_PATH_TRACE, AL_LIGHT_TRACE, AL_INSTANT_RADIOSITY = 0, 1, 2
 DM_ALGORITHM, DM_NORMALS, DM_ALBEDO, DM_DIRECT = 0, 1, 2, 3
 FT_BOX, FT_GAUSSIAN, FT_MITCHELL_NETRAVALI = 0, 1, 2
+STREAM_OWN = C.c_void_p(-1).value      # RTX_STREAM_OWN of include/rtx.h: rtx_set_stream back to the context's own stream
 BSDF_DIFFUSE, BSDF_MIRROR, BSDF_CONDUCTOR, BSDF_GLASS, BSDF_PLASTIC, BSDF_DIELECTRIC, BSDF_ORENNAYAR = 0, 1, 2, 3, 4, 5, 6
 BSDF_LAYERED = 0x100   # OR-ed onto the base type: LayeredBSDF forwards to its base but is two-sided
 
@@ -273,7 +274,9 @@ class Core:
         self._check(self.lib.rtx_set_settings(self.ctx, C.byref(s)))
 
     def set_stream(self, stream_ptr):
-        self._check(self.lib.rtx_set_stream(self.ctx, C.c_void_p(stream_ptr)))
+        """Work goes to the hipStream_t `stream_ptr` from now on. None or 0 is HIP's null stream (as for any hipStream_t);
+        STREAM_OWN gives the context its own non-blocking stream back."""
+        self._check(self.lib.rtx_set_stream(self.ctx, C.c_void_p(stream_ptr or 0)))
 
     def synchronize(self):
         self._check(self.lib.rtx_synchronize(self.ctx))

@@ -112,13 +112,15 @@ struct CopyPool {
     const std::function<void(uint64_t, uint64_t)>* fn = nullptr;
     uint64_t n = 0, per = 0, generation = 0;
     int pending = 0;
+    bool stop = false;
     explicit CopyPool(int threads)
     {
         for (int id = 0; id < threads; id++) workers.emplace_back([this, id]() {
             uint64_t seen = 0;
             std::unique_lock<std::mutex> lk(m);
             for (;;) {
-                cv_work.wait(lk, [&] { return generation != seen; });
+                cv_work.wait(lk, [&] { return stop || generation != seen; });
+                if (stop) return;
                 seen = generation;
                 const uint64_t b = (uint64_t)id * per, e = std::min(n, b + per);
                 const auto* f = fn;
@@ -128,7 +130,12 @@ struct CopyPool {
                 if (--pending == 0) cv_done.notify_one();
             }
         });
-        for (auto& t : workers) t.detach();
+    }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv_work.notify_all();
+        for (auto& t : workers) t.join();
     }
     void run(uint64_t count, const std::function<void(uint64_t, uint64_t)>& f)
     {
@@ -141,11 +148,22 @@ struct CopyPool {
         cv_done.wait(lk, [&] { return pending == 0; });
     }
 };
+// The pool belongs to the contexts: the first host-buffer call makes it, the last rtx_destroy joins its threads.
+std::mutex g_pool_mutex;
+CopyPool* g_pool = nullptr;
+int g_contexts = 0;
 CopyPool& copy_pool()
 {
-    // never destroyed: its threads wait on it until the process ends
-    static CopyPool* pool = new CopyPool((int)std::min(16u, std::max(2u, std::thread::hardware_concurrency())));
-    return *pool;
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    if (!g_pool) g_pool = new CopyPool((int)std::min(16u, std::max(2u, std::thread::hardware_concurrency())));
+    return *g_pool;
+}
+void context_born() { std::lock_guard<std::mutex> lk(g_pool_mutex); g_contexts++; }
+void context_gone()
+{
+    CopyPool* last = nullptr;
+    { std::lock_guard<std::mutex> lk(g_pool_mutex); if (--g_contexts == 0) { last = g_pool; g_pool = nullptr; } }
+    delete last;            // joins the threads (outside the lock: nothing else can reach the pool any more)
 }
 } // namespace
 
@@ -164,6 +182,7 @@ int rtx_create(rtx_ctx** out, int device)
     HIP_TRY(hipSetDevice(device));
     rtx_ctx* c = new (std::nothrow) rtx_ctx;
     if (!c) return fail(RTX_ERR_NOMEM, "out of host memory");
+    context_born();
     const int rc = create_resources(c, device);
     if (rc) { rtx_destroy(c); return rc; }      // streams, events and buffers made so far are released (g_err keeps the cause)
     *out = c;
@@ -242,6 +261,7 @@ void rtx_destroy(rtx_ctx* c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
+    context_gone();
 }
 
 int rtx_set_stream(rtx_ctx* c, void* s)
@@ -414,20 +434,24 @@ int rtx_render_passes(rtx_ctx* c, int n)
     HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
     for (int l = 1; l < lanes; l++) HIP_TRY(hipStreamWaitEvent(ls[l], c->ev_fork, 0));
     const rtx_settings& st = c->settings;
+    // an error in the middle leaves passes enqueued on the other lanes: nothing returns before they have drained
+    auto drain = [&]() { for (int l = 0; l < lanes; l++) (void)hipStreamSynchronize(ls[l]); };
+#define RTX_PIPE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { drain(); return fail(RTX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
     for (int i = 0; i < n; i++) {
         const int l = i % lanes;
         int rc = wavefront_render_pass(c, l, ls[l], i > 0 ? c->pipe_film[(i - 1) % lanes] : nullptr, c->pipe_film[l], false);
-        if (rc) return fail(rc, "render pass failed: %s", hipGetErrorString(hipGetLastError()));
+        if (rc) { const hipError_t e = hipGetLastError(); drain(); return fail(rc, "render pass failed: %s", hipGetErrorString(e)); }
         if (c->spp == (int)st.init_spp && st.algorithm != RTX_AL_LIGHT_TRACE && st.shard_mode != 2) {
             // the adaptive sample targets were just computed on this lane: later passes read them
-            HIP_TRY(hipEventRecord(c->ev_tiles, ls[l]));
-            for (int k = 0; k < lanes; k++) if (k != l) HIP_TRY(hipStreamWaitEvent(ls[k], c->ev_tiles, 0));
+            RTX_PIPE_TRY(hipEventRecord(c->ev_tiles, ls[l]));
+            for (int k = 0; k < lanes; k++) if (k != l) RTX_PIPE_TRY(hipStreamWaitEvent(ls[k], c->ev_tiles, 0));
         }
     }
     for (int l = 1; l < lanes; l++) {
-        HIP_TRY(hipEventRecord(c->pipe_done[l], ls[l]));
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->pipe_done[l], 0));
+        RTX_PIPE_TRY(hipEventRecord(c->pipe_done[l], ls[l]));
+        RTX_PIPE_TRY(hipStreamWaitEvent(c->stream, c->pipe_done[l], 0));
     }
+#undef RTX_PIPE_TRY
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RTX_OK;
 }

@@ -20,6 +20,7 @@
 #include <unordered_map>
 
 #include <sys/wait.h>
+#include <signal.h>
 #include <unistd.h>
 
 #include "RayTracerHost.h"
@@ -210,8 +211,15 @@ int main(int argc, char* argv[])
         }
         if (!child) {
             for (int r = 1; r < gpus; r++) { close(pipes[(size_t)r][0]); close(pipes[(size_t)r][1]); }
-            int worst = 0;
-            for (pid_t k : kids) { int st = 0; waitpid(k, &st, 0); worst = std::max(worst, WIFEXITED(st) ? WEXITSTATUS(st) : 1); }
+            // whichever rank ends first: if it failed, the others would wait for it in a collective for ever, so they are ended too
+            int worst = 0; size_t left = kids.size();
+            while (left > 0) {
+                int st = 0; const pid_t done = waitpid(-1, &st, 0);
+                if (done < 0) break;
+                left--;
+                const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 1;
+                if (code != 0 && worst == 0) { worst = code; for (pid_t k : kids) if (k != done) kill(k, SIGTERM); }
+            }
             return worst;
         }
         for (int r = 1; r < gpus; r++) {

@@ -115,3 +115,23 @@ def test_fly_through_camera_yaw(tmp_path, pkg, lib, core, scenes):
     assert not np.allclose(f2, 0)
     err = np.abs(film - f2) / np.maximum(np.abs(f2), 1e-2)
     assert np.mean((err > 1e-3).any(axis=-1)) < 0.02
+
+
+def test_a_rank_that_dies_takes_the_others_with_it(tmp_path, scenes):
+    """rt_headless -gpus 2 on a box with ONE GPU: rank 1 finds no device and exits with an error while rank 0 waits for
+    it in the RCCL rendezvous. The parent must end rank 0 and report the failure instead of waiting for ever."""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a box with exactly one GPU")
+    sc, kw = scenes.cornell_box(), scenes.cornell_camera()
+    path = str(tmp_path / "b.rtxs")
+    sc.save(path, kw["frm"], kw["to"], kw["up"], kw["fov"], 32, 24)
+    p = subprocess.Popen([APP, "-scene", path, "-outputFilename", str(tmp_path / "o.hdr"), "-SPP", "2", "-gpus", "2", "-quiet", "1"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=90)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, 9)
+        p.communicate()
+        pytest.fail("rt_headless -gpus 2 kept waiting after one of its ranks had failed")
+    assert p.returncode != 0, (out, err)

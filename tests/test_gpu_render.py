@@ -291,3 +291,22 @@ def test_device_matches_frozen_path_vectors(pkg, lib, core, scenes):
     scale = np.abs(gold["lt_film"]).max()
     assert ((np.abs(lt - gold["lt_film"]) > 1e-4 * scale + 1e-4 * np.abs(gold["lt_film"])).any(-1)).mean() <= 0.001
     assert abs(float(lt.sum()) - float(gold["lt_film"].sum())) <= 1e-4 * float(gold["lt_film"].sum())
+
+
+def test_set_stream_null_user_and_own(pkg, lib, core, scenes):
+    """rtx_set_stream: a caller's stream, HIP's null stream (None / 0) and STREAM_OWN (back to the context's own
+    non-blocking stream) all carry the work; the film does not depend on the stream it was rendered on."""
+    import torch
+    core.upload_scene(scenes.cornell_box("mixed"))
+    core.set_camera(pkg.look_at(lib, width=64, height=48, **scenes.cornell_camera()))
+    core.set_settings(pkg.make_settings(total_spp=3, seed=11))
+    films = []
+    user = torch.cuda.Stream()
+    for stream in (pkg.STREAM_OWN, user.cuda_stream, None, pkg.STREAM_OWN):
+        core.set_stream(stream)
+        core.clear(); core.render_passes(3)
+        films.append(core.film()[0])
+    core.set_stream(pkg.STREAM_OWN)
+    assert films[0].sum() > 0
+    for f in films[1:]:
+        assert np.array_equal(f, films[0])

@@ -28,8 +28,11 @@ def test_noalloc_closest_hit_equals_allocating_entry_point(pkg, lib, core, scene
         torch.cuda.synchronize()
         core.trace_closest_device(rays.data_ptr(), n, want.data_ptr())
         core.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
         core.trace_closest_device_noalloc(rays.data_ptr(), n, got.data_ptr())
         core.synchronize()
+        # what the entry point exists for: the call takes no device memory (hipMemGetInfo sees every hipMalloc of the process)
+        assert torch.cuda.mem_get_info()[0] == free_before, "the no-allocation entry point allocated device memory"
         w = want.cpu().numpy().view(pkg.HIT_DTYPE); g = got.cpu().numpy().view(pkg.HIT_DTYPE)
         assert (w["id"] != 0xFFFFFFFF).sum() > n // 10
         assert np.array_equal(g.view(np.uint8), w.view(np.uint8)), f"{(g['id'] != w['id']).sum()} of {n} hit ids differ"
