@@ -416,6 +416,7 @@ int rtx_render_passes(rtx_ctx* c, int n)
     // the passes fill each other's idle lanes. The film is still summed in pass order.
     const int lanes = std::max(1, std::min(n, c->pipeline));
     c->passes_in_flight = lanes;
+    for (int l = 0; l < lanes; l++) { int rc = wavefront_alloc(c, l, c->settings); if (rc) return fail(rc, "path state: allocation failed"); }
     if (c->spill_lanes < 2) { c->spill_lanes = 2; int rc = ensure_spill(c); if (rc) return rc; }
     if (lanes == 1) {
         for (int i = 0; i < n; i++) {
@@ -425,8 +426,6 @@ int rtx_render_passes(rtx_ctx* c, int n)
         HIP_TRY(hipStreamSynchronize(c->stream));
         return RTX_OK;
     }
-    for (int l = 1; l < lanes; l++)
-        if (!c->wf[l]) { int rc = wavefront_alloc(c, l); if (rc) return fail(rc, "wavefront buffers: allocation failed"); }
     if (c->spill_lanes < 2 * lanes) { c->spill_lanes = 2 * lanes; int rc = ensure_spill(c); if (rc) return rc; }
     // lane 0 runs on the caller's stream itself, the others on streams of their own
     hipStream_t ls[kPipeline];
@@ -783,6 +782,7 @@ int rtx_count_render_work(rtx_ctx* c, int n_passes, uint64_t out[8])
     std::vector<uint32_t> q(2 * 96 * kQueueStride);
     const bool radiosity = c->settings.algorithm == RTX_AL_INSTANT_RADIOSITY && c->settings.draw_mode == RTX_DM_ALGORITHM;
     c->count_work = true; c->passes_in_flight = 1;
+    { int rc = wavefront_alloc(c, 0, c->settings); if (rc) { c->count_work = false; return fail(rc, "path state: allocation failed"); } }
     for (int i = 0; i < n_passes; i++) {
         const uint64_t before = c->stats.samples;
         int rc = wavefront_render_pass(c, 0, c->stream, nullptr, nullptr, false);

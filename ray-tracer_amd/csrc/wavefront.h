@@ -51,6 +51,9 @@ struct WfPtrs {
     float* film; uint32_t* tile_samples;
     uint32_t* tile_off;   // [n_tiles] queue offset of the tile's first camera sample this pass
     uint32_t P, W, H, tiles_x, n_tiles, vpl_slots;
+    // Path slots exist for the tiles this context renders only: local tile l = slot / 256 is film tile l * tile_mul + tile_add
+    // (every tile, mul 1 add 0, unless the tiles are split over GPUs: then the tiles t % world == rank, mul = world, add = rank)
+    uint32_t tile_mul, tile_add, n_local_tiles;
 };
 
 struct WavefrontBuffers {
@@ -88,9 +91,10 @@ __device__ __forceinline__ uint32_t queue_slot(bool push, uint32_t* counter)
     return push ? at : 0xFFFFFFFFu;
 }
 
-__device__ __forceinline__ void slot_pixel(uint32_t slot, uint32_t tiles_x, uint32_t& tile, uint32_t& x, uint32_t& y)
+__device__ __forceinline__ void slot_pixel(const WfPtrs& wf, uint32_t slot, uint32_t& tile, uint32_t& x, uint32_t& y)
 {
-    tile = slot >> 8;
+    const uint32_t tiles_x = wf.tiles_x;
+    tile = (slot >> 8) * wf.tile_mul + wf.tile_add;
     const uint32_t j = slot & 255u, w = j >> 6, l = j & 63u;
     x = (tile % tiles_x) * 16u + (((w & 1u) << 3) | (l & 7u));
     y = (tile / tiles_x) * 16u + (((w >> 1) << 3) | (l >> 3));
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(WfPtrs w, CameraDev cam, Pass
     const uint32_t slot = global_thread();
     bool active = false; uint32_t tile = 0, x = 0, y = 0;
     if (slot < w.P) {
-        slot_pixel(slot, w.tiles_x, tile, x, y);
+        slot_pixel(w, slot, tile, x, y);
         active = x < w.W && y < w.H && tile_active(w, pp, tile);
     }
     if (slot < w.P) w.flags[slot] = 0;
@@ -223,11 +227,11 @@ __global__ __launch_bounds__(kBlock) void k_raygen(WfPtrs w, CameraDev cam, Pass
 __global__ __launch_bounds__(1024) void k_tile_offsets(WfPtrs w, PassParams pp)
 {
     __shared__ uint32_t s_part[1024];
-    const uint32_t per = (w.n_tiles + 1023u) / 1024u, t0 = threadIdx.x * per;
+    const uint32_t per = (w.n_local_tiles + 1023u) / 1024u, t0 = threadIdx.x * per;
     uint32_t sum = 0;
     for (uint32_t k = 0; k < per; k++) {
-        const uint32_t tile = t0 + k;
-        if (tile < w.n_tiles && tile_active(w, pp, tile)) {
+        const uint32_t lt = t0 + k, tile = lt * w.tile_mul + w.tile_add;
+        if (lt < w.n_local_tiles && tile_active(w, pp, tile)) {
             const uint32_t sx = (tile % w.tiles_x) * 16u, sy = (tile / w.tiles_x) * 16u;
             sum += (min(sx + 16u, w.W) - sx) * (min(sy + 16u, w.H) - sy);
         }
@@ -242,9 +246,9 @@ __global__ __launch_bounds__(1024) void k_tile_offsets(WfPtrs w, PassParams pp)
     }
     uint32_t run = s_part[threadIdx.x] - sum;
     for (uint32_t k = 0; k < per; k++) {
-        const uint32_t tile = t0 + k;
-        if (tile < w.n_tiles) {
-            w.tile_off[tile] = run;
+        const uint32_t lt = t0 + k, tile = lt * w.tile_mul + w.tile_add;
+        if (lt < w.n_local_tiles) {
+            w.tile_off[lt] = run;
             if (tile_active(w, pp, tile)) {
                 const uint32_t sx = (tile % w.tiles_x) * 16u, sy = (tile / w.tiles_x) * 16u;
                 run += (min(sx + 16u, w.W) - sx) * (min(sy + 16u, w.H) - sy);
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(kBlock) void k_film_accumulate_box(WfPtrs w, int ph
     const uint32_t slot = global_thread();
     if (slot >= w.P || !(w.flags[slot] & kFlagStarted)) return;
     uint32_t tile, x, y;
-    slot_pixel(slot, w.tiles_x, tile, x, y);
+    slot_pixel(w, slot, tile, x, y);
     const float fx = w.xy[2 * slot], fy = w.xy[2 * slot + 1];
     const int px = (int)fx, py = (int)fy;
     const bool own = px == (int)x && py == (int)y;
@@ -521,7 +525,7 @@ __global__ __launch_bounds__(kBlock) void k_lt_emit(WfPtrs w, DeviceScene sc, Ca
     const uint32_t slot = global_thread();
     bool active = false, conn = false; uint32_t tile = 0, x = 0, y = 0; V3 p = mk(0, 0, 0); float fx = 0, fy = 0; C3 cval = mkc(0, 0, 0);
     if (slot < w.P) {
-        slot_pixel(slot, w.tiles_x, tile, x, y);
+        slot_pixel(w, slot, tile, x, y);
         active = x < w.W && y < w.H && tile_active(w, pp, tile) && sc.n_lights > 0;
         w.flags[slot] = 0;
     }
@@ -980,12 +984,20 @@ __global__ __launch_bounds__(kBlock) void k_aov_color(WfPtrs w, float* __restric
 
 inline void wavefront_release(rtx_ctx* c) { for (auto& wf : c->wf) { delete wf; wf = nullptr; } }
 
-// Path state of pipeline lane `lane` for the current camera
-inline int wavefront_alloc(rtx_ctx* c, int lane)
+// Path state of pipeline lane `lane` for the current camera and the tiles `st` makes this context render: every tile of
+// the film, or with the tiles split over GPUs (shard_mode 1) only the context's own, so that the per-pass sweeps over the
+// slots (ray generation, film accumulation) and the memory shrink with the number of ranks. Buffers only ever grow.
+inline int wavefront_alloc(rtx_ctx* c, int lane, const rtx_settings& st)
 {
     if (!c->wf[lane]) c->wf[lane] = new WavefrontBuffers;
     WavefrontBuffers& b = *c->wf[lane];
-    const size_t P = (size_t)c->tiles_x * c->tiles_y * 256;
+    const uint32_t n_tiles = c->tiles_x * c->tiles_y;
+    const bool split = st.shard_mode == 1 && st.shard_world > 1;
+    const uint32_t mul = split ? (uint32_t)st.shard_world : 1u, add = split ? (uint32_t)st.shard_rank : 0u;
+    const uint32_t n_local = n_tiles > add ? (n_tiles - add + mul - 1u) / mul : 0u;
+    // (the light paths of instant radiosity use slots of their own: numThreads x vplRaysPerTile of them, Renderer.h:280-302)
+    const size_t vpl_paths = st.algorithm == RTX_AL_INSTANT_RADIOSITY ? (size_t)st.vpl_rays_per_tile * st.num_threads : 0;
+    const size_t P = std::max<size_t>(std::max<size_t>((size_t)n_local * 256, (vpl_paths + 255) / 256 * 256), 256);
 #define RTX_ENS(buf, bytes) do { if ((buf).ensure(bytes) != hipSuccess) return RTX_ERR_NOMEM; } while (0)
     RTX_ENS(b.ray, P * sizeof(rtx_ray)); RTX_ENS(b.hit, P * sizeof(rtx_hit)); RTX_ENS(b.T, P * 12); RTX_ENS(b.L, P * 12);
     RTX_ENS(b.xy, P * 8); RTX_ENS(b.key, P * 4); RTX_ENS(b.dim, P * 4); RTX_ENS(b.mis, P * 4); RTX_ENS(b.flags, P * 4);
@@ -999,26 +1011,26 @@ inline int wavefront_alloc(rtx_ctx* c, int lane)
     p.sseg = b.sseg.as<float>(); p.sval = b.sval.as<float>(); p.sxy = b.sxy.as<float>(); p.spath = b.spath.as<uint32_t>();
     p.vpl_total = b.vpl_total.as<uint32_t>(); p.tile_off = b.tile_off.as<uint32_t>();
     p.film = c->b_film.as<float>(); p.tile_samples = c->b_tile_samples.as<uint32_t>();
-    p.P = (uint32_t)P; p.W = (uint32_t)c->cam.width; p.H = (uint32_t)c->cam.height; p.tiles_x = c->tiles_x; p.n_tiles = c->tiles_x * c->tiles_y;
+    p.P = (uint32_t)n_local * 256u; p.W = (uint32_t)c->cam.width; p.H = (uint32_t)c->cam.height; p.tiles_x = c->tiles_x; p.n_tiles = n_tiles;
+    p.tile_mul = mul; p.tile_add = add; p.n_local_tiles = n_local;
     return RTX_OK;
 }
 
-// New camera / film size: lane 0 is rebuilt, the other lanes are dropped until a call needs them
+// New camera / film size: the path state of the old size is dropped; rendering calls size it again for what they need
 inline int wavefront_resize(rtx_ctx* c)
 {
-    for (int i = 1; i < kPipeline; i++) { delete c->wf[i]; c->wf[i] = nullptr; }
-    int rc = wavefront_alloc(c, 0);
-    if (rc) return rc;
+    for (int i = 0; i < kPipeline; i++) { delete c->wf[i]; c->wf[i] = nullptr; }
     // tileSamples.resize(totalTiles, 1), RTBase/Renderer.h:112
-    std::vector<uint32_t> ones(c->wf[0]->p.n_tiles, 1u);
+    std::vector<uint32_t> ones((size_t)c->tiles_x * c->tiles_y, 1u);
     if (hipMemcpy(c->b_tile_samples.p, ones.data(), ones.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return RTX_ERR_HIP;
     return RTX_OK;
 }
 
 inline int wavefront_tile_samples(rtx_ctx* c, hipStream_t stream)
 {
-    if (!c->wf[0]) return RTX_ERR_STATE;
-    WfPtrs& w = c->wf[0]->p;
+    WfPtrs w{};         // the kernel reads the film geometry only
+    w.film = c->b_film.as<float>(); w.tile_samples = c->b_tile_samples.as<uint32_t>();
+    w.W = (uint32_t)c->cam.width; w.H = (uint32_t)c->cam.height; w.tiles_x = c->tiles_x; w.n_tiles = c->tiles_x * c->tiles_y;
     hipLaunchKernelGGL(k_tile_samples, dim3((w.n_tiles + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, w, c->spp, c->settings.total_spp);
     return hipGetLastError() == hipSuccess ? RTX_OK : RTX_ERR_HIP;
 }
@@ -1028,7 +1040,10 @@ inline int wavefront_tile_samples(rtx_ctx* c, hipStream_t stream)
 // centres (:699-720 with DM_ALBEDO / DM_NORMALS), rendered into the plane instead of the film.
 inline int wavefront_aov(rtx_ctx* c, float* color, float* albedo, float* normal)
 {
-    if (!c->wf[0]) return RTX_ERR_STATE;
+    {   // every tile of the film, whatever share of it this context renders
+        rtx_settings whole = c->settings; whole.algorithm = RTX_AL_PATH_TRACE; whole.shard_mode = 0; whole.shard_world = 1; whole.shard_rank = 0;
+        int rc = wavefront_alloc(c, 0, whole); if (rc) return rc;
+    }
     WfPtrs w = c->wf[0]->p; hipStream_t s = c->stream;
     const dim3 blk(kBlock), gridP((w.P + kBlock - 1) / kBlock), gridQ(std::min<uint32_t>((w.P + kBlock - 1) / kBlock, kMaxGridBlocks)),
                gridT(std::min<uint32_t>((w.P + kBlock - 1) / kBlock, (uint32_t)c->resident_blocks));
@@ -1180,7 +1195,6 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
     } else {
         // radiosityVplPass, RTBase/Renderer.h:280-302: numThreads x vplRaysPerTile light paths
         const uint32_t n_paths = st.vpl_rays_per_tile * st.num_threads;
-        if (n_paths > w.P) return RTX_ERR_INVALID;
         const uint32_t slots = n_paths * (st.max_bounces + 1);
         if (b.vpl.ensure(std::max<size_t>((size_t)slots * 80, 16)) != hipSuccess) return RTX_ERR_NOMEM;
         w.vpl = b.vpl.as<float>(); w.vplc = w.vpl + 10 * (size_t)slots; w.vpl_slots = slots;
