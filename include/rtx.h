@@ -283,6 +283,23 @@ int rtx_trace_visible_device(rtx_ctx* ctx, const float* p1p2_dev, size_t n, uint
 int rtx_generate_primary_rays_device(rtx_ctx* ctx, rtx_ray* rays_dev, uint32_t* pixel_dev,
                                      size_t n_capacity);
 
+/* ---- function-level parity tables (test support; host buffers, blocking) ------------ */
+
+/* Scene::calculateShadingData, RTBase/Scene.h:183-213, for n (ray, hit) pairs:
+ * out[i] = x(3) wo(3) sNormal(3) gNormal(3) tu tv frame.u(3) frame.v(3) frame.w(3) material index (24 floats; zeros on a miss). */
+int rtx_debug_shading_data(rtx_ctx* ctx, const rtx_ray* rays, const rtx_hit* hits, size_t n, float* out);
+
+/* BSDF::sample / evaluate / PDF, RTBase/Materials.h:139-724, of material `material` on a table of inputs:
+ * in[i] = normal(3) wo(3) tu tv wi_eval(3) u0 u1 u2 (14 floats; u* are what Sampler::next() returns, in call order,
+ * cyclic); out[i] = sampled wi(3) colour(3) pdf, evaluate(wi_eval)(3), PDF(wi_eval) (11 floats). */
+int rtx_debug_bsdf_table(rtx_ctx* ctx, uint32_t material, const float* in, size_t n, float* out);
+
+/* EnvironmentMap::sample, RTBase/Lights.h:252-277,338, on n (u0, u1) pairs: out[i] = wi(3) pdf Le(3); needs an
+ * environment map. Light::evaluate / PDF of the background, RTBase/Lights.h:101-108,344-366, on n directions:
+ * out[i] = Le(3) pdf. */
+int rtx_debug_env_sample(rtx_ctx* ctx, const float* u01, size_t n, float* out);
+int rtx_debug_env_eval(rtx_ctx* ctx, const float* dirs, size_t n, float* out);
+
 /* ---- introspection ---------------------------------------------------------------- */
 
 /* The binary tree exactly as BVHTree keeps it (RTBase/Geometry.h:293-304): per node

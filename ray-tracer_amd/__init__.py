@@ -186,6 +186,8 @@ def load_library(path: str = "") -> C.CDLL:
         "rtx_get_bvh": [vp, C.POINTER(C.c_uint32), vp, vp, vp],
         "rtx_create_aov": [vp, vp, vp, vp], "rtx_create_aov_device": [vp, vp, vp, vp],
         "rtx_get_stats": [vp, C.POINTER(Stats)], "rtx_reset_stats": [vp],
+        "rtx_debug_shading_data": [vp, vp, vp, sz, vp], "rtx_debug_bsdf_table": [vp, C.c_uint32, vp, sz, vp],
+        "rtx_debug_env_sample": [vp, vp, sz, vp], "rtx_debug_env_eval": [vp, vp, sz, vp],
         "rtx_timer_begin": [vp], "rtx_timer_end": [vp, C.POINTER(C.c_float)],
         "rtx_count_closest_work": [vp, vp, sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
         "rtx_count_render_work": [vp, C.c_int, C.POINTER(C.c_uint64)],
@@ -366,6 +368,31 @@ class Core:
         out = (C.c_uint64 * 8)()
         self._check(self.lib.rtx_count_render_work(self.ctx, n_passes, out))
         return dict(zip(("closest_rays", "shadow_rays", "nodes", "tris", "samples", "tri_groups", "gather_segments", "vpls"), (int(v) for v in out)))
+
+    # function-level parity tables (layouts in include/rtx.h)
+    def debug_shading_data(self, rays, hits):
+        rays = np.ascontiguousarray(rays); hits = np.ascontiguousarray(hits)
+        out = np.empty((rays.shape[0], 24), np.float32)
+        self._check(self.lib.rtx_debug_shading_data(self.ctx, rays.ctypes.data, hits.ctypes.data, rays.shape[0], out.ctypes.data))
+        return out
+
+    def debug_bsdf_table(self, material: int, table):
+        t = np.ascontiguousarray(table, np.float32).reshape(-1, 14)
+        out = np.empty((t.shape[0], 11), np.float32)
+        self._check(self.lib.rtx_debug_bsdf_table(self.ctx, material, t.ctypes.data, t.shape[0], out.ctypes.data))
+        return out
+
+    def debug_env_sample(self, u01):
+        u = np.ascontiguousarray(u01, np.float32).reshape(-1, 2)
+        out = np.empty((u.shape[0], 7), np.float32)
+        self._check(self.lib.rtx_debug_env_sample(self.ctx, u.ctypes.data, u.shape[0], out.ctypes.data))
+        return out
+
+    def debug_env_eval(self, dirs):
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        out = np.empty((d.shape[0], 4), np.float32)
+        self._check(self.lib.rtx_debug_env_eval(self.ctx, d.ctypes.data, d.shape[0], out.ctypes.data))
+        return out
 
     # introspection
     def bvh(self):

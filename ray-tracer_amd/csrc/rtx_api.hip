@@ -18,6 +18,7 @@
 #include "trace_kernels.h"
 #include "bvh_device.h"
 #include "wavefront.h"
+#include "debug_tables.h"
 
 using namespace rtx;
 
@@ -815,6 +816,52 @@ int rtx_count_render_work(rtx_ctx* c, int n_passes, uint64_t out[8])
     }
 #endif
     return RTX_OK;
+}
+
+// ---- function-level parity tables (test support) ------------------------------------------
+
+int rtx_debug_shading_data(rtx_ctx* c, const rtx_ray* rays, const rtx_hit* hits, size_t n, float* out)
+{
+    CTX_TRY(c);
+    if (!c->have_scene) return fail(RTX_ERR_STATE, "no scene uploaded");
+    if (n == 0) return RTX_OK;
+    if (!rays || !hits || !out || n > (1u << 26)) return fail(RTX_ERR_INVALID, "bad argument");
+    const uint32_t n_tris = c->dscene.n_tris;
+    for (size_t i = 0; i < n; i++) if (hits[i].t < FLT_MAX && hits[i].id >= n_tris) return fail(RTX_ERR_INVALID, "hit %zu names triangle %u of %u", i, hits[i].id, n_tris);
+    return debug_table(c, rays, n * sizeof(rtx_ray), hits, n * sizeof(rtx_hit), out, n * 24 * sizeof(float), [&](void* a, void* b, void* o) {
+        hipLaunchKernelGGL(k_debug_shading_data, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->dscene, (const rtx_ray*)a, (const rtx_hit*)b, (uint32_t)n, (float*)o); });
+}
+
+int rtx_debug_bsdf_table(rtx_ctx* c, uint32_t material, const float* in, size_t n, float* out)
+{
+    CTX_TRY(c);
+    if (!c->have_scene) return fail(RTX_ERR_STATE, "no scene uploaded");
+    if (n == 0) return RTX_OK;
+    if (!in || !out || n > (1u << 26)) return fail(RTX_ERR_INVALID, "bad argument");
+    if (material >= c->host.materials.size()) return fail(RTX_ERR_INVALID, "material %u of %zu", material, c->host.materials.size());
+    return debug_table(c, in, n * 14 * sizeof(float), nullptr, 0, out, n * 11 * sizeof(float), [&](void* a, void*, void* o) {
+        hipLaunchKernelGGL(k_debug_bsdf_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->dscene, material, (const float*)a, (uint32_t)n, (float*)o); });
+}
+
+int rtx_debug_env_sample(rtx_ctx* c, const float* u01, size_t n, float* out)
+{
+    CTX_TRY(c);
+    if (!c->have_scene) return fail(RTX_ERR_STATE, "no scene uploaded");
+    if (c->dscene.bg_kind != 2) return fail(RTX_ERR_STATE, "the scene has no environment map");
+    if (n == 0) return RTX_OK;
+    if (!u01 || !out || n > (1u << 26)) return fail(RTX_ERR_INVALID, "bad argument");
+    return debug_table(c, u01, n * 2 * sizeof(float), nullptr, 0, out, n * 7 * sizeof(float), [&](void* a, void*, void* o) {
+        hipLaunchKernelGGL(k_debug_env_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->dscene, (const float*)a, (uint32_t)n, (float*)o); });
+}
+
+int rtx_debug_env_eval(rtx_ctx* c, const float* dirs, size_t n, float* out)
+{
+    CTX_TRY(c);
+    if (!c->have_scene) return fail(RTX_ERR_STATE, "no scene uploaded");
+    if (n == 0) return RTX_OK;
+    if (!dirs || !out || n > (1u << 26)) return fail(RTX_ERR_INVALID, "bad argument");
+    return debug_table(c, dirs, n * 3 * sizeof(float), nullptr, 0, out, n * 4 * sizeof(float), [&](void* a, void*, void* o) {
+        hipLaunchKernelGGL(k_debug_env_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->dscene, (const float*)a, (uint32_t)n, (float*)o); });
 }
 
 // ---- introspection -----------------------------------------------------------------------

@@ -168,8 +168,10 @@ RTX_DI float orenNayarTerm(const MaterialDev& m, float thetaI, float phiI, float
     return (m.alpha + m.on_b * cpos * sinf(hi * tanf(lo)));
 }
 
-// BSDF::sample, RTBase/Materials.h:148,193,251,372,451,504,588
-RTX_DI V3 bsdf_sample(const DeviceScene& sc, const Shading& sd, Rng& rng, C3& col, float& pdf)
+// BSDF::sample, RTBase/Materials.h:148,193,251,372,451,504,588. Sampler: anything with next() (the counter generator in
+// the renderer, a list of given numbers in the function-level parity tables)
+template <class Sampler>
+RTX_DI V3 bsdf_sample(const DeviceScene& sc, const Shading& sd, Sampler& rng, C3& col, float& pdf)
 {
     const MaterialDev& m = *sd.mat;
     if (m.type == RTX_BSDF_DIFFUSE || m.type == RTX_BSDF_DIELECTRIC) {
@@ -401,7 +403,8 @@ RTX_DI int cdf_search_guided(const float* cdf, int n, const uint32_t* guide, flo
     while (left < right) { int mid = left + (right - left) / 2; if (cdf[mid] < value) left = mid + 1; else right = mid; }
     return left;
 }
-RTX_DI V3 env_sample(const DeviceScene& sc, Rng& rng, C3& emitted, float& pdf)    // Lights.h:252-277, 330-336
+template <class Sampler>
+RTX_DI V3 env_sample(const DeviceScene& sc, Sampler& rng, C3& emitted, float& pdf)    // Lights.h:252-277, 330-336
 {
     unsigned row = cdf_search_guided(sc.env_cdf_rows, sc.env_h, sc.env_guide_rows, rng.next());
     unsigned col = cdf_search_guided(sc.env_cdf_cols + (size_t)row * sc.env_w, sc.env_w, sc.env_guide_cols + (size_t)row * (sc.env_w + 1), rng.next());
