@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--pt-total-spp", type=int, default=0, help="path-trace leg with this many passes IN TOTAL, split over the ranks (strong scaling); overrides --pt-spp")
     ap.add_argument("--no-radiosity", action="store_true", help="skip the instant-radiosity side measurement")
     ap.add_argument("--variants", default="", help="A/B: comma list of RTX_VARIANT values, interleaved rounds in one process")
+    ap.add_argument("--ab-env", default="", help="A/B: NAME=v1,v2,... varies this tuning switch instead of RTX_VARIANT (which stays at the first --variants value)")
     ap.add_argument("--ab-scene", default="soup", choices=["soup", "mixed"])
     ap.add_argument("--ab-repeat", type=int, default=1, help="A/B: trace the ray set this many times in one launch (tail measurement)")
     ap.add_argument("--ab-count", type=int, default=0, help="A/B: keep only this many rays (random subset)")
@@ -328,11 +329,21 @@ def ab_variants(pkg, lib, scene, cam, args, rays, hits, n, torch, local_rank):
     """Interleaved rounds of the closest-hit kernel under different RTX_VARIANT schedules
     (one context each, same rays), median and min kernel ms per variant."""
     cores = {}
-    for v in [int(x) for x in args.variants.split(",")]:
-        os.environ["RTX_VARIANT"] = str(v)
-        c = pkg.Core(local_rank, lib)
-        c.upload_scene(scene); c.set_camera(cam)
-        cores[v] = c
+    if args.ab_env:
+        name, values = args.ab_env.split("=")
+        os.environ["RTX_VARIANT"] = args.variants.split(",")[0]
+        for v in values.split(","):
+            os.environ[name] = v
+            c = pkg.Core(local_rank, lib)
+            c.upload_scene(scene); c.set_camera(cam)
+            cores[f"{name}={v}"] = c
+        del os.environ[name]
+    else:
+        for v in [int(x) for x in args.variants.split(",")]:
+            os.environ["RTX_VARIANT"] = str(v)
+            c = pkg.Core(local_rank, lib)
+            c.upload_scene(scene); c.set_camera(cam)
+            cores[v] = c
     ref = None
     times = {v: [] for v in cores}
     for rnd in range(7):
