@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Live paths and shadow segments per path depth of one 1080p pass of the mixed-material scene (tuning build:
+RTX_LIBRARY=tuning RTX_DEBUG_COUNTERS=1 python tools/pt_counts.py), printed on stderr by the library."""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("RTX_LIBRARY", "tuning")
+os.environ.setdefault("RTX_DEBUG_COUNTERS", "1")
+pkg = importlib.import_module("ray-tracer_amd")
+scenes = importlib.import_module("ray-tracer_amd.scenes")
+lib = pkg.load_library()
+core = pkg.Core(0, lib)
+core.upload_scene(scenes.mixed_scene(128))
+core.set_camera(pkg.look_at(lib, width=1920, height=1080, **scenes.mixed_camera()))
+core.set_settings(pkg.make_settings(total_spp=100000, seed=1, use_mis=1, max_bounces=5))
+core.clear()
+print(core.count_render_work(1))
