@@ -87,8 +87,6 @@ struct rtx_ctx {
     uint32_t tiles_x = 0, tiles_y = 0;
     rtx::WavefrontBuffers* wf[rtx::kPipeline] = {};   // path state of the passes in flight; [0] always exists once a camera is set
     int pipeline = 3;                                  // passes rtx_render_passes keeps in flight (RTX_PIPELINE); 3 + the caller's stream fit the 4 hardware queues
-    int split_single = 1;                              // a call for one pass enqueues it as `pipeline` shares of its tiles (RTX_SPLIT_SINGLE=0: as one)
-    uint32_t split_grid_div = 1;                       // (tuning) traversal grid of a share = resident workgroups / this
     int passes_in_flight = 1;                          // set by rtx_render_passes for the passes it is enqueueing
     int spill_lanes = 1;                               // traversal-stack slabs in b_spill
     hipStream_t pipe_stream[rtx::kPipeline] = {};

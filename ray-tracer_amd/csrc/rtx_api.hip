@@ -231,8 +231,6 @@ static int create_resources(rtx_ctx* c, int device)
     if (const char* v = tuning_env("RTX_MERGE")) c->merge_shadow = atoi(v) != 0;
     if (const char* v = tuning_env("RTX_RAYS_PER_BLOCK")) c->rays_per_block = std::max(1, std::min(kBlock, atoi(v)));
     if (const char* v = tuning_env("RTX_PIPELINE")) c->pipeline = std::max(1, std::min(kPipeline, atoi(v)));
-    if (const char* v = tuning_env("RTX_SPLIT_SINGLE")) c->split_single = atoi(v);
-    if (const char* v = tuning_env("RTX_SPLIT_GRID_DIV")) c->split_grid_div = (uint32_t)std::max(1, atoi(v));
     HIP_TRY(c->b_counters.ensure(4 * 5 * kWorkSlotWords));   // instrumentation counters, then the work-counter slots of the closest-hit, visibility and packet launches (+ the length of the packet kernel's rest queue)
     // RayTracer's defaults, RTBase/Settings.h:40-61
     rtx_settings& s = c->settings;
@@ -418,43 +416,6 @@ int rtx_render_passes(rtx_ctx* c, int n)
     // own: late bounces hold few rays and a launch then lasts as long as its slowest ray, so
     // the passes fill each other's idle lanes. The film is still summed in pass order.
     const int lanes = std::max(1, std::min(n, c->pipeline));
-    // One pass per call (what RayTracer::renderMT is): the pass is enqueued as c->pipeline shares of its tiles, each with
-    // streams and path state of its own, so that the sparse late depths of one share (a traversal launch lasts at least
-    // as long as its slowest ray) run beside the busy early depths of another. Same samples, same film sums.
-    {
-        const rtx_settings& st = c->settings;
-        const uint32_t world = (st.shard_mode == 1 && st.shard_world > 1) ? (uint32_t)st.shard_world : 1u;
-        const uint32_t local_tiles = c->tiles_x * c->tiles_y / world;
-        const uint32_t parts = (uint32_t)c->pipeline;
-        if (n == 1 && parts > 1 && c->split_single && st.draw_mode == RTX_DM_ALGORITHM && st.algorithm != RTX_AL_INSTANT_RADIOSITY && local_tiles >= 64u * parts) {
-            c->passes_in_flight = (int)parts;
-            for (uint32_t l = 0; l < parts; l++) { int rc = wavefront_alloc(c, (int)l, st, l, parts); if (rc) return fail(rc, "path state: allocation failed"); }
-            if (c->spill_lanes < 2 * (int)parts) { c->spill_lanes = 2 * (int)parts; int rc = ensure_spill(c); if (rc) return rc; }
-            hipStream_t ls[kPipeline];
-            for (uint32_t l = 0; l < parts; l++) ls[l] = l == 0 ? c->stream : c->pipe_stream[l];
-            auto drain = [&]() { for (uint32_t l = 0; l < parts; l++) (void)hipStreamSynchronize(ls[l]); };
-#define RTX_PART_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { drain(); return fail(RTX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
-            RTX_PART_TRY(hipEventRecord(c->ev_fork, c->stream));
-            for (uint32_t l = 1; l < parts; l++) RTX_PART_TRY(hipStreamWaitEvent(ls[l], c->ev_fork, 0));
-            // stage by stage over the shares where the pass has stages (the share enqueued last then starts a few launches
-            // after the first one, not a whole pass's worth of launches later)
-            const bool staged = wavefront_stages_supported(c);
-            const uint32_t n_stages = staged ? st.max_bounces + 2u : 1u;
-            for (uint32_t sg = 0; sg < n_stages; sg++)
-                for (uint32_t l = 0; l < parts; l++) {
-                    int rc = staged ? wavefront_render_pass(c, (int)l, ls[l], nullptr, nullptr, false, l, parts, sg, sg) : wavefront_render_pass(c, (int)l, ls[l], nullptr, nullptr, false, l, parts);
-                    if (rc) { const hipError_t e = hipGetLastError(); drain(); return fail(rc, "render pass failed: %s", hipGetErrorString(e)); }
-                }
-            for (uint32_t l = 1; l < parts; l++) {
-                RTX_PART_TRY(hipEventRecord(c->pipe_done[l], ls[l]));
-                RTX_PART_TRY(hipStreamWaitEvent(c->stream, c->pipe_done[l], 0));
-            }
-#undef RTX_PART_TRY
-            { int rc = wavefront_finish_parts(c, parts, c->stream); if (rc) { drain(); return fail(rc, "film accumulation failed"); } }
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            return RTX_OK;
-        }
-    }
     c->passes_in_flight = lanes;
     for (int l = 0; l < lanes; l++) { int rc = wavefront_alloc(c, l, c->settings); if (rc) return fail(rc, "path state: allocation failed"); }
     if (c->spill_lanes < 2) { c->spill_lanes = 2; int rc = ensure_spill(c); if (rc) return rc; }

@@ -987,15 +987,13 @@ inline void wavefront_release(rtx_ctx* c) { for (auto& wf : c->wf) { delete wf; 
 // Path state of pipeline lane `lane` for the current camera and the tiles `st` makes this context render: every tile of
 // the film, or with the tiles split over GPUs (shard_mode 1) only the context's own, so that the per-pass sweeps over the
 // slots (ray generation, film accumulation) and the memory shrink with the number of ranks. Buffers only ever grow.
-// parts > 1: the lane renders share `part` of `parts` of those tiles (every parts-th one), see rtx_render_passes.
-inline int wavefront_alloc(rtx_ctx* c, int lane, const rtx_settings& st, uint32_t part = 0, uint32_t parts = 1)
+inline int wavefront_alloc(rtx_ctx* c, int lane, const rtx_settings& st)
 {
     if (!c->wf[lane]) c->wf[lane] = new WavefrontBuffers;
     WavefrontBuffers& b = *c->wf[lane];
     const uint32_t n_tiles = c->tiles_x * c->tiles_y;
     const bool split = st.shard_mode == 1 && st.shard_world > 1;
-    const uint32_t world = split ? (uint32_t)st.shard_world : 1u;
-    const uint32_t mul = world * parts, add = (split ? (uint32_t)st.shard_rank : 0u) + world * part;
+    const uint32_t mul = split ? (uint32_t)st.shard_world : 1u, add = split ? (uint32_t)st.shard_rank : 0u;
     const uint32_t n_local = n_tiles > add ? (n_tiles - add + mul - 1u) / mul : 0u;
     // (the light paths of instant radiosity use slots of their own: numThreads x vplRaysPerTile of them, Renderer.h:280-302)
     const size_t vpl_paths = st.algorithm == RTX_AL_INSTANT_RADIOSITY ? (size_t)st.vpl_rays_per_tile * st.num_threads : 0;
@@ -1072,21 +1070,12 @@ inline int wavefront_aov(rtx_ctx* c, float* color, float* albedo, float* normal)
 // One pass on pipeline lane `lane`, enqueued on stream s. Film sums of consecutive passes are
 // kept in pass order (float addition does not commute bit for bit): the pass waits for
 // film_wait before it touches the film and records film_signal when it has.
-// parts > 1: this call enqueues share `part` of the pass only (the lane's path state covers that share of the tiles,
-// wavefront_alloc); part 0 advances the sample count, and the caller adds the samples to the film and computes the
-// adaptive targets once all shares are done (wavefront_finish_parts).
-// A path-tracing pass is max_bounces + 2 stages (stage d <= max_bounces: the traversal launch and the shade kernel of
-// depth d, ray generation before stage 0; the last stage: the shadow rays of the last depth and the film); a call can
-// enqueue the stages [stage_lo, stage_hi] only, so that the caller can interleave the shares of a pass stage by stage
-// (the host enqueues ~17 launches per share, and the share enqueued last would otherwise start that much later).
-inline bool wavefront_stages_supported(const rtx_ctx* c) { return c->settings.draw_mode == RTX_DM_ALGORITHM && c->settings.algorithm == RTX_AL_PATH_TRACE && c->merge_shadow; }
-inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t film_wait, hipEvent_t film_signal, bool overlap, uint32_t part = 0, uint32_t parts = 1,
-                                 uint32_t stage_lo = 0, uint32_t stage_hi = 0xFFFFFFFFu)
+inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t film_wait, hipEvent_t film_signal, bool overlap)
 {
     if (!c->wf[lane]) return RTX_ERR_STATE;
     WavefrontBuffers& b = *c->wf[lane]; WfPtrs& w = b.p; const rtx_settings& st = c->settings;
     const dim3 blk(kBlock), gridP((w.P + kBlock - 1) / kBlock), gridQ(std::min<uint32_t>((w.P + kBlock - 1) / kBlock, kMaxGridBlocks)),
-               gridT(std::min<uint32_t>((w.P + kBlock - 1) / kBlock, std::max(1u, (uint32_t)c->resident_blocks / (parts > 1 ? c->split_grid_div : 1u))));   // traversal kernels fetch work dynamically
+               gridT(std::min<uint32_t>((w.P + kBlock - 1) / kBlock, (uint32_t)c->resident_blocks));   // traversal kernels fetch work dynamically
     const uint32_t sstride = kMaxGridBlocks * kBlock;
     uint2* spill = c->b_spill.as<uint2>() + (size_t)(2 * lane) * c->spill_entries * sstride;
     uint2* spill_aux = spill + (size_t)c->spill_entries * sstride;      // traversal stacks of the kernels on the lane's second stream
@@ -1096,12 +1085,10 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
     DeviceScene dscene = c->dscene;
     if (c->passes_in_flight > 1) dscene.spread_below = std::min<uint32_t>(dscene.spread_below, 2u);
 
-    const bool first = stage_lo == 0, last = stage_hi >= st.max_bounces + 1u;
-    if (!(first && last) && !wavefront_stages_supported(c)) return RTX_ERR_STATE;
-    if (part == 0 && first) c->spp++;                    // Film::incrementSPP, RTBase/Imaging.h:403
+    c->spp++;                                            // Film::incrementSPP, RTBase/Imaging.h:403
     PassParams pp; pp.st = st; pp.spp = c->spp; pp.depth = 0;
     pp.sample_index = (st.shard_mode == 2 && st.shard_world > 1) ? (uint32_t)(c->spp - 1) * (uint32_t)st.shard_world + (uint32_t)st.shard_rank + 1u : (uint32_t)c->spp;
-    if (first && hipMemsetAsync(w.cnt, 0, kCounterWords * 4, s) != hipSuccess) return RTX_ERR_HIP;
+    if (hipMemsetAsync(w.cnt, 0, kCounterWords * 4, s) != hipSuccess) return RTX_ERR_HIP;
 
     const bool cw = c->count_work;                       // instrumented kernels (rtx_count_render_work)
     unsigned long long* ctr = cw ? c->b_counters.as<unsigned long long>() : nullptr;
@@ -1142,24 +1129,22 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         launch_film_accumulate(w, (int)st.filter, gridP, blk, s);
         c->stats.samples += (uint64_t)w.W * w.H;
     } else if (st.algorithm == RTX_AL_PATH_TRACE) {
-        if (first) {
-            hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, w, pp);
-            hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
-        }
+        hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, w, pp);
+        hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
         uint32_t* qin = w.qa; uint32_t* qout = w.qb;
         if (c->merge_shadow) {
             // closest(0), shade(0), then per depth ONE traversal launch for the shadow rays of depth d - 1 and the
             // closest hits of depth d, shade(d); the shadow rays of the last depth go alone
-            for (uint32_t d = stage_lo; d <= std::min(stage_hi, st.max_bounces + 1u); d++) {
-                if (d > st.max_bounces) { shadow(s, (uint32_t)(kShadowCounterBase + st.max_bounces), (uint32_t)(kShadowWorkBase + st.max_bounces * kWorkSlotWords), spill); break; }
-                qin = (d & 1u) ? w.qb : w.qa; qout = (d & 1u) ? w.qa : w.qb;
+            for (uint32_t d = 0; d <= st.max_bounces; d++) {
                 pp.depth = d;
                 if (d == 0) closest_primary();
                 else if (cw) hipLaunchKernelGGL(k_pt_trace_mixed<true>, gridT, blk, 0, s, w, dscene, d, (const uint32_t*)qin, (uint32_t)(kClosestWorkBase + d * kWorkSlotWords), spill, sstride, ctr);
                 else hipLaunchKernelGGL(k_pt_trace_mixed<false>, gridT, blk, 0, s, w, dscene, d, (const uint32_t*)qin, (uint32_t)(kClosestWorkBase + d * kWorkSlotWords), spill, sstride,
                                         (unsigned long long*)nullptr);
                 hipLaunchKernelGGL(k_pt_shade, gridQ, blk, 0, s, w, dscene, pp, (const uint32_t*)qin, qout);
+                std::swap(qin, qout);
             }
+            shadow(s, (uint32_t)(kShadowCounterBase + st.max_bounces), (uint32_t)(kShadowWorkBase + st.max_bounces * kWorkSlotWords), spill);
         } else {
         // The shadow rays of depth d and the closest hits of depth d + 1 do not depend on each other:
         // the former run on the lane's second stream. The shade kernel of depth d + 1 waits for them
@@ -1178,11 +1163,9 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         }
         if (overlap && hipStreamWaitEvent(s, c->ev_shadow[lane], 0) != hipSuccess) return RTX_ERR_HIP;
         }
-        if (parts == 1 && last) {
-            if (film_wait && hipStreamWaitEvent(s, film_wait, 0) != hipSuccess) return RTX_ERR_HIP;
-            launch_film_accumulate(w, (int)st.filter, gridP, blk, s);
-        }
-        if (part == 0 && first) c->stats.samples += (uint64_t)w.W * w.H;
+        if (film_wait && hipStreamWaitEvent(s, film_wait, 0) != hipSuccess) return RTX_ERR_HIP;
+        launch_film_accumulate(w, (int)st.filter, gridP, blk, s);
+        c->stats.samples += (uint64_t)w.W * w.H;
     } else if (st.algorithm == RTX_AL_LIGHT_TRACE) {
         hipLaunchKernelGGL(k_lt_emit, gridP, blk, 0, s, w, dscene, c->dcam, pp);
         uint32_t* qin = w.qa; uint32_t* qout = w.qb;
@@ -1208,7 +1191,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
                 std::swap(qin, qout);
             }
         }
-        if (part == 0) c->stats.samples += (uint64_t)w.W * w.H;
+        c->stats.samples += (uint64_t)w.W * w.H;
     } else {
         // radiosityVplPass, RTBase/Renderer.h:280-302: numThreads x vplRaysPerTile light paths
         const uint32_t n_paths = st.vpl_rays_per_tile * st.num_threads;
@@ -1259,32 +1242,12 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         c->stats.samples += (uint64_t)w.W * w.H;
     }
     if (hipGetLastError() != hipSuccess) return RTX_ERR_HIP;
-    if (!last) return RTX_OK;
     // RTBase/Renderer.h:780-781
-    if (parts == 1 && c->spp == (int)st.init_spp && st.algorithm != RTX_AL_LIGHT_TRACE && st.shard_mode != 2) {
+    if (c->spp == (int)st.init_spp && st.algorithm != RTX_AL_LIGHT_TRACE && st.shard_mode != 2) {
         int rc = wavefront_tile_samples(c, s);
         if (rc) return rc;
     }
     if (film_signal && hipEventRecord(film_signal, s) != hipSuccess) return RTX_ERR_HIP;
-    return RTX_OK;
-}
-
-// End of a pass that was enqueued as `parts` shares on lanes 0 .. parts - 1 (all of them joined into stream s): the
-// samples go to the film in the order one whole pass adds them (box filter: every share's samples that stay in their
-// pixel first, the strays afterwards), then the adaptive targets.
-inline int wavefront_finish_parts(rtx_ctx* c, uint32_t parts, hipStream_t s)
-{
-    const rtx_settings& st = c->settings;
-    const dim3 blk(kBlock);
-    if (st.algorithm != RTX_AL_LIGHT_TRACE) {
-        if (st.filter == RTX_FT_BOX) {
-            for (int phase = 0; phase < 2; phase++)
-                for (uint32_t l = 0; l < parts; l++) { const WfPtrs& w = c->wf[l]->p; hipLaunchKernelGGL(k_film_accumulate_box, dim3((w.P + kBlock - 1) / kBlock), blk, 0, s, w, phase); }
-        } else
-            for (uint32_t l = 0; l < parts; l++) { const WfPtrs& w = c->wf[l]->p; hipLaunchKernelGGL(k_film_accumulate, dim3((w.P + kBlock - 1) / kBlock), blk, 0, s, w, (int)st.filter); }
-        if (hipGetLastError() != hipSuccess) return RTX_ERR_HIP;
-    }
-    if (c->spp == (int)st.init_spp && st.algorithm != RTX_AL_LIGHT_TRACE && st.shard_mode != 2) return wavefront_tile_samples(c, s);
     return RTX_OK;
 }
 
