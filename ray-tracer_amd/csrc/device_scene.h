@@ -23,8 +23,12 @@ struct TriShade {
     float gsign;                 // sign applied by Triangle::gNormal, Geometry.h:158-161
     uint32_t material;
     float area;                  // Geometry.h:87
-    float pad[3];
+    uint32_t shade_class;        // what a hit on the triangle asks of the shade kernels (kClass*): lets them group their items before the material is read
+    float pad[2];
 };
+// classes of shade-kernel items, ordered by how much work they are: a miss, a hit on an emitter, a hit on a purely
+// specular surface (no next-event estimation, RTBase/Renderer.h:420-423), then the surfaces that sample a light by BSDF
+constexpr uint32_t kClassMiss = 0, kClassLight = 1, kClassSpecular = 2, kClassDiffuse = 3, kClassOrenNayar = 4, kClassConductor = 5, kClassPlastic = 6, kClassCount = 7;
 static_assert(sizeof(TriShade) == 96, "TriShade layout");
 
 // Material record after the constructors of RTBase/Materials.h have run.

@@ -196,6 +196,9 @@ std::string prepare_scene(const rtx_scene_desc& d, HostScene& hs, const Bvh2Buil
         s.gsign = dot3(f3(s.n0), n) > 0 ? 1.0f : -1.0f;                                            // Geometry.h:158-161
         s.area = len3(c) * 0.5f;
         s.material = d.material_index[i];
+        const MaterialDev& m = hs.materials[s.material];
+        s.shade_class = m.is_light ? kClassLight : (m.type == RTX_BSDF_MIRROR || m.type == RTX_BSDF_GLASS) ? kClassSpecular : m.type == RTX_BSDF_ORENNAYAR ? kClassOrenNayar
+                        : m.type == RTX_BSDF_CONDUCTOR ? kClassConductor : m.type == RTX_BSDF_PLASTIC ? kClassPlastic : kClassDiffuse;
     } });
 
     auto t1 = std::chrono::steady_clock::now();

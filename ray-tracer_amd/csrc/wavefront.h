@@ -258,17 +258,69 @@ __global__ __launch_bounds__(1024) void k_tile_offsets(WfPtrs w, PassParams pp)
     if (threadIdx.x == 1023u) w.cnt[(0) * kQueueStride] = s_part[1023];
 }
 
-// One depth of RayTracer::pathTrace, RTBase/Renderer.h:476-526, for every live path.
-__global__ __launch_bounds__(kBlock) void k_pt_shade(WfPtrs w, DeviceScene sc, PassParams pp, const uint32_t* __restrict__ qin, uint32_t* qout)
+// The items of a shade kernel's workgroup regrouped by class (miss, emitter, specular surface, one class per BSDF that
+// samples a light). After the first bounce the queue holds paths in arrival order, and a wave whose 64 paths are a few
+// surface hits among misses walks the long chain of dependent loads of a surface hit (triangle record, material, texel,
+// light, CDF rows and columns, environment texels) for a handful of lanes and the short one of a miss for the others.
+// Sorted, the waves of a workgroup are pure but for the ones at class boundaries. A counting sort: ballots per class,
+// per-wave counts and a prefix in LDS; the path slot and the hit record travel through LDS to the lane that shades them.
+struct ShadeRegroup {
+    uint32_t slot[kBlock], id[kBlock]; float t[kBlock], alpha[kBlock], beta[kBlock], gamma[kBlock];
+    uint32_t count[kBlock / 64][8], base[kBlock / 64][8], total;
+};
+// every thread of the workgroup calls this from uniform control flow; returns whether the thread has an item afterwards
+__device__ __forceinline__ bool regroup_by_class(ShadeRegroup& s, bool active, uint32_t cls, uint32_t& slot, rtx_hit& h)
 {
+    static_assert(kClassCount <= 8, "eight counters per wave");
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t rank = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < 8u; c++) {
+        const unsigned long long m = __ballot(active && cls == c);
+        if (lane == c) s.count[wave][c] = (uint32_t)__popcll(m);
+        if (cls == c) rank = (uint32_t)__popcll(m & below);
+    }
+    __syncthreads();
+    if (threadIdx.x < (kBlock / 64) * 8) {
+        const uint32_t wv = threadIdx.x >> 3, c = threadIdx.x & 7u;
+        uint32_t b = 0;
+        for (uint32_t cc = 0; cc < c; cc++) for (uint32_t ww = 0; ww < kBlock / 64; ww++) b += s.count[ww][cc];
+        for (uint32_t ww = 0; ww < wv; ww++) b += s.count[ww][c];
+        s.base[wv][c] = b;
+        if (threadIdx.x == (kBlock / 64) * 8 - 1) s.total = b + s.count[wv][c];      // last wave, last class: everything before it + its own
+    }
+    __syncthreads();
+    if (active) {
+        const uint32_t p = s.base[wave][cls] + rank;
+        s.slot[p] = slot; s.id[p] = h.id; s.t[p] = h.t; s.alpha[p] = h.alpha; s.beta[p] = h.beta; s.gamma[p] = h.gamma;
+    }
+    __syncthreads();
+    const bool mine = threadIdx.x < s.total;
+    if (mine) { const uint32_t p = threadIdx.x; slot = s.slot[p]; h.id = s.id[p]; h.t = s.t[p]; h.alpha = s.alpha[p]; h.beta = s.beta[p]; h.gamma = s.gamma[p]; }
+    return mine;
+}
+
+// One depth of RayTracer::pathTrace, RTBase/Renderer.h:476-526, for every live path. REGROUP: the workgroup sorts its
+// items by class first (camera rays arrive in pixel-block order and are coherent as they are).
+template <bool REGROUP>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pt_shade(WfPtrs w, DeviceScene sc, PassParams pp, const uint32_t* __restrict__ qin, uint32_t* qout)
+{
+    __shared__ ShadeRegroup s_regroup;
     const uint32_t n = w.cnt[(pp.depth) * kQueueStride];
     const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
     for (uint32_t it = 0; it < rounds; it++) {
         const uint32_t i = it * gridDim.x * kBlock + global_thread();
         bool cont = false, shadow = false; uint32_t slot = 0; V3 p2 = mk(0, 0, 0); C3 sval = mkc(0, 0, 0); V3 sx = mk(0, 0, 0);
-        if (i < n) {
-            slot = qin[i];
-            const rtx_hit h = w.hit[slot]; const rtx_ray r = w.ray[slot];
+        bool have = i < n; rtx_hit h; h.id = 0; h.t = FLT_MAX; h.alpha = h.beta = h.gamma = 0.0f;
+        if (have) { slot = qin[i]; h = w.hit[slot]; }
+        if constexpr (REGROUP) {
+            uint32_t cls = kClassMiss;
+            if (have && h.t < FLT_MAX) cls = sc.shade[h.id].shade_class;
+            have = regroup_by_class(s_regroup, have, cls, slot, h);
+        }
+        if (have) {
+            const rtx_ray r = w.ray[slot];
             C3 T = ldc(w.T + 3 * slot); C3 L = ldc(w.L + 3 * slot);
             const uint32_t flags = w.flags[slot]; const float misPdf = w.mis[slot];
             const uint32_t rkey = w.key[slot], rdim = w.dim[slot];
@@ -1141,7 +1193,8 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
                 else if (cw) hipLaunchKernelGGL(k_pt_trace_mixed<true>, gridT, blk, 0, s, w, dscene, d, (const uint32_t*)qin, (uint32_t)(kClosestWorkBase + d * kWorkSlotWords), spill, sstride, ctr);
                 else hipLaunchKernelGGL(k_pt_trace_mixed<false>, gridT, blk, 0, s, w, dscene, d, (const uint32_t*)qin, (uint32_t)(kClosestWorkBase + d * kWorkSlotWords), spill, sstride,
                                         (unsigned long long*)nullptr);
-                hipLaunchKernelGGL(k_pt_shade, gridQ, blk, 0, s, w, dscene, pp, (const uint32_t*)qin, qout);
+                if (d >= c->regroup_from_depth) hipLaunchKernelGGL(k_pt_shade<true>, gridQ, blk, 0, s, w, dscene, pp, (const uint32_t*)qin, qout);
+                else hipLaunchKernelGGL(k_pt_shade<false>, gridQ, blk, 0, s, w, dscene, pp, (const uint32_t*)qin, qout);
                 std::swap(qin, qout);
             }
             shadow(s, (uint32_t)(kShadowCounterBase + st.max_bounces), (uint32_t)(kShadowWorkBase + st.max_bounces * kWorkSlotWords), spill);
@@ -1155,7 +1208,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
             pp.depth = d;
             closest(qin, d);
             if (overlap && d > 0 && hipStreamWaitEvent(s, c->ev_shadow[lane], 0) != hipSuccess) return RTX_ERR_HIP;
-            hipLaunchKernelGGL(k_pt_shade, gridQ, blk, 0, s, w, dscene, pp, (const uint32_t*)qin, qout);
+            hipLaunchKernelGGL(k_pt_shade<false>, gridQ, blk, 0, s, w, dscene, pp, (const uint32_t*)qin, qout);
             if (overlap && (hipEventRecord(c->ev_shade[lane], s) != hipSuccess || hipStreamWaitEvent(sa, c->ev_shade[lane], 0) != hipSuccess)) return RTX_ERR_HIP;
             shadow(sa, (uint32_t)(kShadowCounterBase + d), (uint32_t)(kShadowWorkBase + d * kWorkSlotWords), overlap ? spill_aux : spill);
             if (overlap && hipEventRecord(c->ev_shadow[lane], sa) != hipSuccess) return RTX_ERR_HIP;
