@@ -87,14 +87,11 @@ struct rtx_ctx {
     uint32_t tiles_x = 0, tiles_y = 0;
     rtx::WavefrontBuffers* wf[rtx::kPipeline] = {};   // path state of the passes in flight; [0] always exists once a camera is set
     int pipeline = 3;                                  // passes rtx_render_passes keeps in flight (RTX_PIPELINE); 3 + the caller's stream fit the 4 hardware queues
-    uint32_t regroup_from_depth = 99;                  // path tracing: the shade kernels from this depth on sort their items by class inside the workgroup (RTX_REGROUP_FROM)
+    uint32_t regroup_from_depth = 1;                   // path tracing: the shade kernels from this depth on sort their items by class inside the workgroup (RTX_REGROUP_FROM)
     int passes_in_flight = 1;                          // set by rtx_render_passes for the passes it is enqueueing
     int spill_lanes = 1;                               // traversal-stack slabs in b_spill
     hipStream_t pipe_stream[rtx::kPipeline] = {};
-    hipStream_t aux_stream[rtx::kPipeline] = {};       // per lane: shadow rays of depth d run beside the closest hits of depth d + 1
-    hipEvent_t ev_shade[rtx::kPipeline] = {}, ev_shadow[rtx::kPipeline] = {};
-    int merge_shadow = 1;                              // path tracing: shadow rays of depth d share a launch with the closest hits of depth d + 1 (RTX_MERGE=0: separate launches)
-    int overlap = 1;                                   // used when a call renders one pass at a time; RTX_OVERLAP=0 keeps a pass on one stream
+    int merge_shadow = 1;                              // light tracing: the camera connections of a depth share a launch with the closest hits of the next (RTX_MERGE=0: separate launches)
     hipEvent_t pipe_film[rtx::kPipeline] = {}, pipe_done[rtx::kPipeline] = {}, ev_fork = nullptr, ev_tiles = nullptr;
 
     bool count_work = false;       // render passes run the instrumented traversal kernels (rtx_count_render_work)

@@ -223,11 +223,7 @@ static int create_resources(rtx_ctx* c, int device)
         HIP_TRY(hipStreamCreateWithFlags(&c->pipe_stream[i], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&c->pipe_film[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->pipe_done[i], hipEventDisableTiming));
-        HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream[i], hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_shade[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_shadow[i], hipEventDisableTiming));
     }
-    if (const char* v = tuning_env("RTX_OVERLAP")) c->overlap = atoi(v) != 0;
     if (const char* v = tuning_env("RTX_MERGE")) c->merge_shadow = atoi(v) != 0;
     if (const char* v = tuning_env("RTX_RAYS_PER_BLOCK")) c->rays_per_block = std::max(1, std::min(kBlock, atoi(v)));
     if (const char* v = tuning_env("RTX_PIPELINE")) c->pipeline = std::max(1, std::min(kPipeline, atoi(v)));
@@ -252,9 +248,6 @@ void rtx_destroy(rtx_ctx* c)
         if (c->pipe_stream[i]) (void)hipStreamDestroy(c->pipe_stream[i]);
         if (c->pipe_film[i]) (void)hipEventDestroy(c->pipe_film[i]);
         if (c->pipe_done[i]) (void)hipEventDestroy(c->pipe_done[i]);
-        if (c->aux_stream[i]) (void)hipStreamDestroy(c->aux_stream[i]);
-        if (c->ev_shade[i]) (void)hipEventDestroy(c->ev_shade[i]);
-        if (c->ev_shadow[i]) (void)hipEventDestroy(c->ev_shadow[i]);
     }
     for (auto& e : c->io_kernel_done) if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -419,16 +412,15 @@ int rtx_render_passes(rtx_ctx* c, int n)
     const int lanes = std::max(1, std::min(n, c->pipeline));
     c->passes_in_flight = lanes;
     for (int l = 0; l < lanes; l++) { int rc = wavefront_alloc(c, l, c->settings); if (rc) return fail(rc, "path state: allocation failed"); }
-    if (c->spill_lanes < 2) { c->spill_lanes = 2; int rc = ensure_spill(c); if (rc) return rc; }
     if (lanes == 1) {
         for (int i = 0; i < n; i++) {
-            int rc = wavefront_render_pass(c, 0, c->stream, nullptr, nullptr, c->overlap != 0);
+            int rc = wavefront_render_pass(c, 0, c->stream, nullptr, nullptr);
             if (rc) return fail(rc, "render pass failed: %s", hipGetErrorString(hipGetLastError()));
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
         return RTX_OK;
     }
-    if (c->spill_lanes < 2 * lanes) { c->spill_lanes = 2 * lanes; int rc = ensure_spill(c); if (rc) return rc; }
+    if (c->spill_lanes < lanes) { c->spill_lanes = lanes; int rc = ensure_spill(c); if (rc) return rc; }
     // lane 0 runs on the caller's stream itself, the others on streams of their own
     hipStream_t ls[kPipeline];
     for (int l = 0; l < lanes; l++) ls[l] = l == 0 ? c->stream : c->pipe_stream[l];
@@ -440,7 +432,7 @@ int rtx_render_passes(rtx_ctx* c, int n)
 #define RTX_PIPE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { drain(); return fail(RTX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
     for (int i = 0; i < n; i++) {
         const int l = i % lanes;
-        int rc = wavefront_render_pass(c, l, ls[l], i > 0 ? c->pipe_film[(i - 1) % lanes] : nullptr, c->pipe_film[l], false);
+        int rc = wavefront_render_pass(c, l, ls[l], i > 0 ? c->pipe_film[(i - 1) % lanes] : nullptr, c->pipe_film[l]);
         if (rc) { const hipError_t e = hipGetLastError(); drain(); return fail(rc, "render pass failed: %s", hipGetErrorString(e)); }
         if (c->spp == (int)st.init_spp && st.algorithm != RTX_AL_LIGHT_TRACE && st.shard_mode != 2) {
             // the adaptive sample targets were just computed on this lane: later passes read them
@@ -779,15 +771,14 @@ int rtx_count_render_work(rtx_ctx* c, int n_passes, uint64_t out[8])
     if (!out || n_passes < 1) return fail(RTX_ERR_INVALID, "bad argument");
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemsetAsync(c->b_counters.p, 0, 4 * kWorkSlotWords, c->stream));
-    if (c->spill_lanes < 2) { c->spill_lanes = 2; int rc = ensure_spill(c); if (rc) return rc; }
     for (int i = 0; i < 8; i++) out[i] = 0;
-    std::vector<uint32_t> q(2 * 96 * kQueueStride);
+    std::vector<uint32_t> q(kCounterWords);
     const bool radiosity = c->settings.algorithm == RTX_AL_INSTANT_RADIOSITY && c->settings.draw_mode == RTX_DM_ALGORITHM;
     c->count_work = true; c->passes_in_flight = 1;
     { int rc = wavefront_alloc(c, 0, c->settings); if (rc) { c->count_work = false; return fail(rc, "path state: allocation failed"); } }
     for (int i = 0; i < n_passes; i++) {
         const uint64_t before = c->stats.samples;
-        int rc = wavefront_render_pass(c, 0, c->stream, nullptr, nullptr, false);
+        int rc = wavefront_render_pass(c, 0, c->stream, nullptr, nullptr);
         hipError_t e = rc ? hipSuccess : hipMemcpyAsync(q.data(), c->wf[0]->p.cnt, q.size() * 4, hipMemcpyDeviceToHost, c->stream);
         uint32_t vpls = 0;
         if (!rc && e == hipSuccess && radiosity) e = hipMemcpyAsync(&vpls, c->wf[0]->p.vpl_total, 4, hipMemcpyDeviceToHost, c->stream);
@@ -796,10 +787,12 @@ int rtx_count_render_work(rtx_ctx* c, int n_passes, uint64_t out[8])
         // queue lengths of the pass: live paths per depth (one closest-hit ray each), shadow / connection segments per depth
         // (instant radiosity: the counters are cleared between the VPL walk and the gather, so its light paths' few rays
         // are not in the sums; queue 1 of the gather holds the gathering pixels, which are no rays)
-        for (int d = 0; d < 96; d++) { if (!(radiosity && d == 1)) out[0] += q[d * kQueueStride]; out[1] += q[(96 + d) * kQueueStride]; }
+        // (dense queues keep their length in one word; the path tracer's queues behind depth 0 in kQueueStreams stream lengths)
+        auto queue_length = [&](uint32_t qi) { uint32_t nq = q[qi * kQueueStride]; for (uint32_t sc = 0; sc < (uint32_t)kQueueStreams; sc++) nq += q[stream_word(qi, sc)]; return nq; };
+        for (uint32_t d = 0; d < 96; d++) { if (!(radiosity && d == 1)) out[0] += queue_length(d); out[1] += queue_length(96 + d); }
         if (i == 0 && tuning_env("RTX_DEBUG_COUNTERS"))
             for (uint32_t d = 0; d <= c->settings.max_bounces + 1u && d < 95u; d++)
-                fprintf(stderr, "[rtx] depth %u: %u live paths, %u shadow / connection segments\n", d, q[d * kQueueStride], q[(96 + d) * kQueueStride]);
+                fprintf(stderr, "[rtx] depth %u: %u live paths, %u shadow / connection segments\n", d, queue_length(d), queue_length(96 + d));
         out[4] += c->stats.samples - before; out[7] += vpls;
     }
     c->count_work = false;
@@ -810,7 +803,7 @@ int rtx_count_render_work(rtx_ctx* c, int n_passes, uint64_t out[8])
     {
         // (the instrumented passes above ran the per-lane gather; one more plain pass for the packet walk's statistics)
         HIP_TRY(hipMemset(c->b_counters.as<unsigned long long>() + 8, 0, 6 * 8));
-        int rc = wavefront_render_pass(c, 0, c->stream, nullptr, nullptr, false);
+        int rc = wavefront_render_pass(c, 0, c->stream, nullptr, nullptr);
         if (rc) return fail(rc, "render pass failed");
         HIP_TRY(hipStreamSynchronize(c->stream));
         unsigned long long p[6];

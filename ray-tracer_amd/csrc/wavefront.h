@@ -31,7 +31,13 @@ constexpr int kShadowCounterBase = 96;
 constexpr int kQueueStride = 32;                                            // queue length q lives in word q * kQueueStride: a 128-byte line of its own
 constexpr int kClosestWorkBase = 192 * kQueueStride;                        // 96 work-counter slots of the closest-hit launches
 constexpr int kShadowWorkBase = kClosestWorkBase + 96 * kWorkSlotWords;     // 96 slots of the shadow / splat launches
-constexpr int kCounterWords = kShadowWorkBase + 96 * kWorkSlotWords;
+// Path tracing keeps every queue behind depth 0 as kQueueStreams streams with a length of their own (see stream_push):
+// queue q, stream c at word stream_word(q, c), a line each like the dense queue lengths
+constexpr int kQueueStreams = 16;
+constexpr int kStreamCounterBase = kShadowWorkBase + 96 * kWorkSlotWords;
+constexpr int kCounterWords = kStreamCounterBase + 192 * kQueueStreams * kQueueStride;
+constexpr int kQueueSlack = kQueueStreams * 64;                             // queue arrays hold P + kQueueSlack entries: streamed queues round up to whole blocks of 64 per stream
+__host__ __device__ constexpr uint32_t stream_word(uint32_t q, uint32_t c) { return (uint32_t)kStreamCounterBase + (q * (uint32_t)kQueueStreams + c) * (uint32_t)kQueueStride; }
 
 struct WfPtrs {
     rtx_ray* ray; rtx_hit* hit;
@@ -89,6 +95,46 @@ __device__ __forceinline__ uint32_t queue_slot(bool push, uint32_t* counter)
     for (uint32_t i = 0; i < wave; i++) at += s_count[i];
     __syncthreads();                        // the next call may overwrite the counts
     return push ? at : 0xFFFFFFFFu;
+}
+
+// Streamed queues. A queue push that costs one atomic per WORKGROUP (queue_slot) makes the waves of a workgroup wait
+// for each other: the wave whose paths all left the scene sits at the barrier until the wave that shades surface hits
+// has walked its chain of dependent loads, and holds its registers meanwhile. One atomic per WAVE needs no barrier, but
+// returning atomics on one address complete at ~90 M/s, far too few for 30 000 waves per launch. So a queue is
+// kQueueStreams streams, each with its own length counter; stream c owns the blocks of 64 queue positions whose index is
+// c modulo kQueueStreams, and a wave appends to one stream with one atomic. A consumer sees positions
+// [0, kQueueStreams * 64 * blocks of the longest stream); position k holds an entry if its place within its stream lies
+// below that stream's length (stream_valid), the rest are holes, skipped at fetch. The producers' choice of stream keeps
+// the streams equally long but for chance, and bounds them: see k_pt_shade.
+__device__ __forceinline__ uint32_t stream_position(uint32_t e, uint32_t c) { return (((e >> 6) * (uint32_t)kQueueStreams + c) << 6) | (e & 63u); }
+struct StreamLens { uint32_t len[kQueueStreams]; };
+// every thread of the workgroup calls this (there is a barrier inside): the lengths of queue q into `s`, returns the number of positions
+__device__ __forceinline__ uint32_t stream_load(const uint32_t* cnt, uint32_t q, StreamLens& s)
+{
+    if (threadIdx.x < (uint32_t)kQueueStreams) s.len[threadIdx.x] = cnt[stream_word(q, threadIdx.x)];
+    __syncthreads();
+    uint32_t blocks = 0;
+#pragma unroll
+    for (int c = 0; c < kQueueStreams; c++) blocks = max(blocks, (s.len[c] + 63u) >> 6);
+    return blocks * (uint32_t)(kQueueStreams * 64);
+}
+__device__ __forceinline__ bool stream_valid(const StreamLens& s, uint32_t k)
+{
+    const uint32_t g = k >> 6;
+    return (((g / (uint32_t)kQueueStreams) << 6) | (k & 63u)) < s.len[g % (uint32_t)kQueueStreams];
+}
+// every lane of the wave calls this from uniform control flow: the pushing lanes take consecutive entries of the stream
+// whose length is *counter; returns the queue position (0xFFFFFFFF for lanes that do not push)
+__device__ __forceinline__ uint32_t stream_push(bool push, uint32_t* counter, uint32_t stream)
+{
+    const unsigned long long m = __ballot(push);
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (m != 0ull) {
+        if (lane == 0) base = atomicAdd(counter, (uint32_t)__popcll(m));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    }
+    return push ? stream_position(base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), stream) : 0xFFFFFFFFu;
 }
 
 __device__ __forceinline__ void slot_pixel(const WfPtrs& wf, uint32_t slot, uint32_t& tile, uint32_t& x, uint32_t& y)
@@ -301,18 +347,28 @@ __device__ __forceinline__ bool regroup_by_class(ShadeRegroup& s, bool active, u
     return mine;
 }
 
-// One depth of RayTracer::pathTrace, RTBase/Renderer.h:476-526, for every live path. REGROUP: the workgroup sorts its
-// items by class first (camera rays arrive in pixel-block order and are coherent as they are).
-template <bool REGROUP>
+// One depth of RayTracer::pathTrace, RTBase/Renderer.h:476-526, for every live path: one queue position per thread.
+// FIRST: the queue of camera samples (dense, its length in the queue word of depth 0); otherwise a streamed queue.
+// REGROUP: the workgroup sorts its items by class first (camera rays arrive in pixel-block order and are coherent as
+// they are). The launch covers every position the queue can have; workgroups beyond its end leave at once.
+// Survivors and shadow rays go to the streamed queues of the next depth, one atomic per wave and no barrier. Wave w
+// of workgroup b appends to stream 4 * (b % 4) + (w + b / 4) % 4: every stream gets exactly one wave of every fourth
+// workgroup, so a stream never grows beyond 64 entries per 1024 input positions (the output needs no more positions
+// than the input had, P + kQueueSlack bounds them all), and the wave that holds the sorted workgroup's surface hits
+// moves round the streams of its group instead of filling one.
+template <bool FIRST, bool REGROUP>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pt_shade(WfPtrs w, DeviceScene sc, PassParams pp, const uint32_t* __restrict__ qin, uint32_t* qout)
 {
     __shared__ ShadeRegroup s_regroup;
-    const uint32_t n = w.cnt[(pp.depth) * kQueueStride];
-    const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
-    for (uint32_t it = 0; it < rounds; it++) {
-        const uint32_t i = it * gridDim.x * kBlock + global_thread();
+    __shared__ StreamLens s_in;
+    uint32_t extent;
+    if constexpr (FIRST) extent = w.cnt[(0) * kQueueStride]; else extent = stream_load(w.cnt, pp.depth, s_in);
+    if (blockIdx.x * (uint32_t)kBlock >= extent) return;
+    {
+        const uint32_t i = global_thread();
         bool cont = false, shadow = false; uint32_t slot = 0; V3 p2 = mk(0, 0, 0); C3 sval = mkc(0, 0, 0); V3 sx = mk(0, 0, 0);
-        bool have = i < n; rtx_hit h; h.id = 0; h.t = FLT_MAX; h.alpha = h.beta = h.gamma = 0.0f;
+        bool have = i < extent; rtx_hit h; h.id = 0; h.t = FLT_MAX; h.alpha = h.beta = h.gamma = 0.0f;
+        if constexpr (!FIRST) have = have && stream_valid(s_in, i);
         if (have) { slot = qin[i]; h = w.hit[slot]; }
         if constexpr (REGROUP) {
             uint32_t cls = kClassMiss;
@@ -362,12 +418,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 st3(w.L + 3 * slot, L);
             }
         }
-        uint32_t qs = queue_slot(shadow, &w.cnt[(kShadowCounterBase + pp.depth) * kQueueStride]);
+        const uint32_t stream = ((blockIdx.x & 3u) << 2) | (((threadIdx.x >> 6) + (blockIdx.x >> 2)) & 3u);
+        const uint32_t qs = stream_push(shadow, w.cnt + stream_word(kShadowCounterBase + pp.depth, stream), stream);
         if (shadow) {
             float* s = w.sseg + 6 * (size_t)qs; s[0] = sx.x; s[1] = sx.y; s[2] = sx.z; s[3] = p2.x; s[4] = p2.y; s[5] = p2.z;
             st3(w.sval + 3 * (size_t)qs, sval); w.spath[qs] = slot;
         }
-        uint32_t qc = queue_slot(cont, &w.cnt[(pp.depth + 1) * kQueueStride]);
+        const uint32_t qc = stream_push(cont, w.cnt + stream_word(pp.depth + 1, stream), stream);
         if (cont) qout[qc] = slot;
     }
 }
@@ -419,13 +476,20 @@ __global__ __launch_bounds__(kBlock) void k_closest_counted(DeviceScene sc, cons
 // least as long as its slowest ray, so one launch for both halves the number of such floors per pass. Items
 // [0, n_closest) are the live paths of `queue`, items from n_closest on the shadow segments.
 struct PtMixedPolicy {
-    const DeviceScene& sc; const WfPtrs& w; const uint32_t* queue; uint32_t n_closest;
+    const DeviceScene& sc; const WfPtrs& w; const uint32_t* queue; uint32_t n_closest; const StreamLens& live; const StreamLens& segs;
     __device__ __forceinline__ bool fetch(uint32_t k, float o[3], float d[3], float& maxT, bool& any) const
     {
+        o[0] = o[1] = o[2] = 0.0f; d[0] = d[1] = d[2] = 0.0f; maxT = 0.0f;
         if (k < n_closest) {
+            any = false;
+            if (!stream_valid(live, k)) return false;              // a hole of the streamed queue
             const rtx_ray r = w.ray[queue[k]];
-            o[0] = r.o[0]; o[1] = r.o[1]; o[2] = r.o[2]; d[0] = r.d[0]; d[1] = r.d[1]; d[2] = r.d[2]; maxT = 0.0f; any = false;
-        } else { segment_to_ray(w.sseg + 6 * (size_t)(k - n_closest), o, d, maxT); any = true; }
+            o[0] = r.o[0]; o[1] = r.o[1]; o[2] = r.o[2]; d[0] = r.d[0]; d[1] = r.d[1]; d[2] = r.d[2];
+        } else {
+            any = true;
+            if (!stream_valid(segs, k - n_closest)) return false;
+            segment_to_ray(w.sseg + 6 * (size_t)(k - n_closest), o, d, maxT);
+        }
         return true;
     }
     __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool reached) const
@@ -440,14 +504,16 @@ struct PtMixedPolicy {
     __device__ __forceinline__ void note(uint32_t, uint32_t, uint32_t) const {}
 };
 // (the per-item flag costs registers: held to the 96 that keep five waves per SIMD like the other traversal kernels; +3 % on a 1080p pass)
+// depth = max_bounces + 1: the live queue of that depth is empty, the launch walks the shadow rays of the last depth
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_pt_trace_mixed(WfPtrs w, DeviceScene sc, uint32_t depth, const uint32_t* __restrict__ queue, uint32_t work_index,
                                                            uint2* spill, uint32_t spill_stride, unsigned long long* counters)
 {
     __shared__ unsigned long long lds[kBlock * kLdsStack];
+    __shared__ StreamLens s_live, s_segs;
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
-    const uint32_t n_closest = w.cnt[(depth) * kQueueStride], n_shadow = w.cnt[(kShadowCounterBase + depth - 1) * kQueueStride];
-    PtMixedPolicy pol{sc, w, queue, n_closest};
+    const uint32_t n_closest = stream_load(w.cnt, depth, s_live), n_shadow = stream_load(w.cnt, kShadowCounterBase + depth - 1, s_segs);
+    PtMixedPolicy pol{sc, w, queue, n_closest, s_live, s_segs};
     __shared__ TailShare<kBlock> ts;
     traverse_dyn<PtMixedPolicy, kModeMixed, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, COUNT ? 0 : kShare>(sc, stk, n_closest + n_shadow, w.cnt + work_index, pol, counters, &ts);
 }
@@ -1053,8 +1119,9 @@ inline int wavefront_alloc(rtx_ctx* c, int lane, const rtx_settings& st)
 #define RTX_ENS(buf, bytes) do { if ((buf).ensure(bytes) != hipSuccess) return RTX_ERR_NOMEM; } while (0)
     RTX_ENS(b.ray, P * sizeof(rtx_ray)); RTX_ENS(b.hit, P * sizeof(rtx_hit)); RTX_ENS(b.T, P * 12); RTX_ENS(b.L, P * 12);
     RTX_ENS(b.xy, P * 8); RTX_ENS(b.key, P * 4); RTX_ENS(b.dim, P * 4); RTX_ENS(b.mis, P * 4); RTX_ENS(b.flags, P * 4);
-    RTX_ENS(b.qa, P * 4); RTX_ENS(b.qb, P * 4); RTX_ENS(b.cnt, kCounterWords * 4);
-    RTX_ENS(b.sseg, P * 24); RTX_ENS(b.sval, P * 12); RTX_ENS(b.sxy, P * 8); RTX_ENS(b.spath, P * 4); RTX_ENS(b.vpl_total, 16); RTX_ENS(b.tile_off, P / 256 * 4);
+    const size_t Q = P + kQueueSlack;      // what is indexed by queue position
+    RTX_ENS(b.qa, Q * 4); RTX_ENS(b.qb, Q * 4); RTX_ENS(b.cnt, kCounterWords * 4);
+    RTX_ENS(b.sseg, Q * 24); RTX_ENS(b.sval, Q * 12); RTX_ENS(b.sxy, P * 8); RTX_ENS(b.spath, Q * 4); RTX_ENS(b.vpl_total, 16); RTX_ENS(b.tile_off, P / 256 * 4);
 #undef RTX_ENS
     WfPtrs& p = b.p;
     p.ray = b.ray.as<rtx_ray>(); p.hit = b.hit.as<rtx_hit>(); p.T = b.T.as<float>(); p.L = b.L.as<float>(); p.xy = b.xy.as<float>();
@@ -1122,15 +1189,14 @@ inline int wavefront_aov(rtx_ctx* c, float* color, float* albedo, float* normal)
 // One pass on pipeline lane `lane`, enqueued on stream s. Film sums of consecutive passes are
 // kept in pass order (float addition does not commute bit for bit): the pass waits for
 // film_wait before it touches the film and records film_signal when it has.
-inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t film_wait, hipEvent_t film_signal, bool overlap)
+inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t film_wait, hipEvent_t film_signal)
 {
     if (!c->wf[lane]) return RTX_ERR_STATE;
     WavefrontBuffers& b = *c->wf[lane]; WfPtrs& w = b.p; const rtx_settings& st = c->settings;
     const dim3 blk(kBlock), gridP((w.P + kBlock - 1) / kBlock), gridQ(std::min<uint32_t>((w.P + kBlock - 1) / kBlock, kMaxGridBlocks)),
                gridT(std::min<uint32_t>((w.P + kBlock - 1) / kBlock, (uint32_t)c->resident_blocks));   // traversal kernels fetch work dynamically
     const uint32_t sstride = kMaxGridBlocks * kBlock;
-    uint2* spill = c->b_spill.as<uint2>() + (size_t)(2 * lane) * c->spill_entries * sstride;
-    uint2* spill_aux = spill + (size_t)c->spill_entries * sstride;      // traversal stacks of the kernels on the lane's second stream
+    uint2* spill = c->b_spill.as<uint2>() + (size_t)lane * c->spill_entries * sstride;
 
     // several passes in flight fill each other's idle lanes: spreading a small launch thin (helpers walking speculative
     // subtrees) then only takes throughput away from the other passes, so it is kept for launches that are nearly empty
@@ -1183,39 +1249,27 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
     } else if (st.algorithm == RTX_AL_PATH_TRACE) {
         hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, w, pp);
         hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
+        // closest(0), shade(0), then per depth ONE traversal launch for the shadow rays of depth d - 1 and the closest
+        // hits of depth d (neither depends on the other, and a traversal launch lasts at least as long as its slowest
+        // ray), shade(d); the launch of depth max_bounces + 1 has the shadow rays of the last depth only.
+        // A shade launch has a thread for every position a queue can have (streamed queues, see stream_push).
+        const dim3 gridS((w.P + 1023u) / 1024u * 4u);
+        auto mixed = [&](uint32_t d, const uint32_t* queue) {
+            if (cw) hipLaunchKernelGGL(k_pt_trace_mixed<true>, gridT, blk, 0, s, w, dscene, d, queue, (uint32_t)(kClosestWorkBase + d * kWorkSlotWords), spill, sstride, ctr);
+            else hipLaunchKernelGGL(k_pt_trace_mixed<false>, gridT, blk, 0, s, w, dscene, d, queue, (uint32_t)(kClosestWorkBase + d * kWorkSlotWords), spill, sstride, (unsigned long long*)nullptr);
+        };
         uint32_t* qin = w.qa; uint32_t* qout = w.qb;
-        if (c->merge_shadow) {
-            // closest(0), shade(0), then per depth ONE traversal launch for the shadow rays of depth d - 1 and the
-            // closest hits of depth d, shade(d); the shadow rays of the last depth go alone
-            for (uint32_t d = 0; d <= st.max_bounces; d++) {
-                pp.depth = d;
-                if (d == 0) closest_primary();
-                else if (cw) hipLaunchKernelGGL(k_pt_trace_mixed<true>, gridT, blk, 0, s, w, dscene, d, (const uint32_t*)qin, (uint32_t)(kClosestWorkBase + d * kWorkSlotWords), spill, sstride, ctr);
-                else hipLaunchKernelGGL(k_pt_trace_mixed<false>, gridT, blk, 0, s, w, dscene, d, (const uint32_t*)qin, (uint32_t)(kClosestWorkBase + d * kWorkSlotWords), spill, sstride,
-                                        (unsigned long long*)nullptr);
-                if (d >= c->regroup_from_depth) hipLaunchKernelGGL(k_pt_shade<true>, gridQ, blk, 0, s, w, dscene, pp, (const uint32_t*)qin, qout);
-                else hipLaunchKernelGGL(k_pt_shade<false>, gridQ, blk, 0, s, w, dscene, pp, (const uint32_t*)qin, qout);
-                std::swap(qin, qout);
-            }
-            shadow(s, (uint32_t)(kShadowCounterBase + st.max_bounces), (uint32_t)(kShadowWorkBase + st.max_bounces * kWorkSlotWords), spill);
-        } else {
-        // The shadow rays of depth d and the closest hits of depth d + 1 do not depend on each other:
-        // the former run on the lane's second stream. The shade kernel of depth d + 1 waits for them
-        // (it adds to the same radiance slots and refills the shadow queue). Worth 16 % when one pass runs
-        // alone; with several passes in flight the extra streams cost more than they give (measured).
-        hipStream_t sa = overlap ? c->aux_stream[lane] : s;
         for (uint32_t d = 0; d <= st.max_bounces; d++) {
             pp.depth = d;
-            closest(qin, d);
-            if (overlap && d > 0 && hipStreamWaitEvent(s, c->ev_shadow[lane], 0) != hipSuccess) return RTX_ERR_HIP;
-            hipLaunchKernelGGL(k_pt_shade<false>, gridQ, blk, 0, s, w, dscene, pp, (const uint32_t*)qin, qout);
-            if (overlap && (hipEventRecord(c->ev_shade[lane], s) != hipSuccess || hipStreamWaitEvent(sa, c->ev_shade[lane], 0) != hipSuccess)) return RTX_ERR_HIP;
-            shadow(sa, (uint32_t)(kShadowCounterBase + d), (uint32_t)(kShadowWorkBase + d * kWorkSlotWords), overlap ? spill_aux : spill);
-            if (overlap && hipEventRecord(c->ev_shadow[lane], sa) != hipSuccess) return RTX_ERR_HIP;
+            if (d == 0) closest_primary(); else mixed(d, qin);
+            const bool regroup = d >= c->regroup_from_depth;
+            if (d == 0) { if (regroup) hipLaunchKernelGGL((k_pt_shade<true, true>), gridS, blk, 0, s, w, dscene, pp, (const uint32_t*)qin, qout);
+                          else hipLaunchKernelGGL((k_pt_shade<true, false>), gridS, blk, 0, s, w, dscene, pp, (const uint32_t*)qin, qout); }
+            else if (regroup) hipLaunchKernelGGL((k_pt_shade<false, true>), gridS, blk, 0, s, w, dscene, pp, (const uint32_t*)qin, qout);
+            else hipLaunchKernelGGL((k_pt_shade<false, false>), gridS, blk, 0, s, w, dscene, pp, (const uint32_t*)qin, qout);
             std::swap(qin, qout);
         }
-        if (overlap && hipStreamWaitEvent(s, c->ev_shadow[lane], 0) != hipSuccess) return RTX_ERR_HIP;
-        }
+        mixed(st.max_bounces + 1u, qin);
         if (film_wait && hipStreamWaitEvent(s, film_wait, 0) != hipSuccess) return RTX_ERR_HIP;
         launch_film_accumulate(w, (int)st.filter, gridP, blk, s);
         c->stats.samples += (uint64_t)w.W * w.H;
