@@ -157,6 +157,21 @@ __device__ __forceinline__ bool tile_active(const WfPtrs& w, const PassParams& p
     return true;
 }
 
+// The camera sample path slot `slot` takes this pass, processTile's per-sample set-up (RTBase/Renderer.h:695-697,
+// 730-731): false if the slot has none (outside the film, or its tile is skipped). The path tracer's kernels that need
+// the sample (closest hit and shade kernel of depth 0, film accumulation) each derive it from the slot number: the
+// generator is a function of (seed, pixel, sample index, dimension), so nothing has to be stored and read back.
+__device__ __forceinline__ bool camera_sample(const WfPtrs& w, const PassParams& pp, uint32_t slot, float& px, float& py, Rng& rng)
+{
+    if (slot >= w.P) return false;
+    uint32_t tile, x, y;
+    slot_pixel(w, slot, tile, x, y);
+    if (!(x < w.W && y < w.H && tile_active(w, pp, tile))) return false;
+    rng.key = rtx_rng_key(pp.st.seed, RTX_STREAM_CAMERA, y * w.W + x, pp.sample_index); rng.dim = 0;
+    px = x + rng.next(); py = y + rng.next();
+    return true;
+}
+
 __device__ __forceinline__ void st3(float* p, C3 c) { p[0] = c.r; p[1] = c.g; p[2] = c.b; }
 __device__ __forceinline__ void st3(float* p, V3 c) { p[0] = c.x; p[1] = c.y; p[2] = c.z; }
 
@@ -357,37 +372,57 @@ __device__ __forceinline__ bool regroup_by_class(ShadeRegroup& s, bool active, u
 // than the input had, P + kQueueSlack bounds them all), and the wave that holds the sorted workgroup's surface hits
 // moves round the streams of its group instead of filling one.
 template <bool FIRST, bool REGROUP>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pt_shade(WfPtrs w, DeviceScene sc, PassParams pp, const uint32_t* __restrict__ qin, uint32_t* qout)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pt_shade(WfPtrs w, DeviceScene sc, CameraDev cam, PassParams pp, const uint32_t* __restrict__ qin, uint32_t* qout)
 {
     __shared__ ShadeRegroup s_regroup;
     __shared__ StreamLens s_in;
     uint32_t extent;
-    if constexpr (FIRST) extent = w.cnt[(0) * kQueueStride]; else extent = stream_load(w.cnt, pp.depth, s_in);
+    if constexpr (FIRST) extent = w.P; else extent = stream_load(w.cnt, pp.depth, s_in);
     if (blockIdx.x * (uint32_t)kBlock >= extent) return;
     {
         const uint32_t i = global_thread();
         bool cont = false, shadow = false; uint32_t slot = 0; V3 p2 = mk(0, 0, 0); C3 sval = mkc(0, 0, 0); V3 sx = mk(0, 0, 0);
         bool have = i < extent; rtx_hit h; h.id = 0; h.t = FLT_MAX; h.alpha = h.beta = h.gamma = 0.0f;
-        if constexpr (!FIRST) have = have && stream_valid(s_in, i);
-        if (have) { slot = qin[i]; h = w.hit[slot]; }
+        if constexpr (FIRST) {
+            // depth 0: position i is path slot i (no queue); whether it carries a sample is decided again below, with the sample itself
+            float px, py; Rng crng;
+            have = camera_sample(w, pp, i, px, py, crng);
+            slot = i;
+            if (have) h = w.hit[slot];
+        } else {
+            have = have && stream_valid(s_in, i);
+            if (have) { slot = qin[i]; h = w.hit[slot]; }
+        }
         if constexpr (REGROUP) {
             uint32_t cls = kClassMiss;
             if (have && h.t < FLT_MAX) cls = sc.shade[h.id].shade_class;
             have = regroup_by_class(s_regroup, have, cls, slot, h);
         }
         if (have) {
-            const rtx_ray r = w.ray[slot];
-            C3 T = ldc(w.T + 3 * slot); C3 L = ldc(w.L + 3 * slot);
-            const uint32_t flags = w.flags[slot]; const float misPdf = w.mis[slot];
-            const uint32_t rkey = w.key[slot], rdim = w.dim[slot];
-            // the whole path state in one round trip: without this the compiler loads each piece where it is first
-            // read, behind the triangle record, the material and the texture, one dependent round trip each
-            asm volatile("" :: "v"(T.r), "v"(T.g), "v"(T.b), "v"(L.r), "v"(L.g), "v"(L.b), "v"(flags), "v"(misPdf), "v"(rkey), "v"(rdim));
-            const V3 o = ld3(r.o), d = ld3(r.d);
+            V3 o, d; C3 T, L; uint32_t flags, rkey, rdim; float misPdf;
+            if constexpr (FIRST) {
+                // the state ray generation would have stored (Renderer.h:730-736): the camera ray of the slot's sample, unit
+                // throughput, no radiance yet, the generator behind the two jitter draws
+                float px, py; Rng crng;
+                camera_sample(w, pp, slot, px, py, crng);
+                float dx, dy, dz; camera_ray(cam, px, py, dx, dy, dz);
+                o = ld3(cam.origin); d = mk(dx, dy, dz);
+                T = mkc(1.0f, 1.0f, 1.0f); L = mkc(0.0f, 0.0f, 0.0f);
+                flags = kFlagStarted | (pp.st.can_hit_light ? kFlagCanHitLight : 0u); misPdf = 0.0f; rkey = crng.key; rdim = crng.dim;
+            } else {
+                const rtx_ray r = w.ray[slot];
+                T = ldc(w.T + 3 * slot); L = ldc(w.L + 3 * slot);
+                flags = w.flags[slot]; misPdf = w.mis[slot];
+                rkey = w.key[slot]; rdim = w.dim[slot];
+                // the whole path state in one round trip: without this the compiler loads each piece where it is first
+                // read, behind the triangle record, the material and the texture, one dependent round trip each
+                asm volatile("" :: "v"(T.r), "v"(T.g), "v"(T.b), "v"(L.r), "v"(L.g), "v"(L.b), "v"(flags), "v"(misPdf), "v"(rkey), "v"(rdim));
+                o = ld3(r.o); d = ld3(r.d);
+            }
             if (h.t < FLT_MAX) {
                 Shading sd; shading_data(sc, h, o, d, sd);
                 if (sd.mat->is_light) {
-                    if (flags & kFlagCanHitLight) { L = L + T * ldc(sd.mat->emission); st3(w.L + 3 * slot, L); }
+                    if (flags & kFlagCanHitLight) { L = L + T * ldc(sd.mat->emission); if constexpr (!FIRST) st3(w.L + 3 * slot, L); }
                 } else {
                     Rng rng; rng.key = rkey; rng.dim = rdim;
                     C3 dv;
@@ -402,6 +437,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                             rtx_ray nr; nr.o[0] = no.x; nr.o[1] = no.y; nr.o[2] = no.z; nr.d[0] = wi.x; nr.d[1] = wi.y; nr.d[2] = wi.z;
                             w.ray[slot] = nr; st3(w.T + 3 * slot, T); w.mis[slot] = pdf;
                             w.flags[slot] = (flags & ~kFlagCanHitLight) | (isPureSpecular(*sd.mat) ? kFlagCanHitLight : 0u);
+                            if constexpr (FIRST) w.key[slot] = rkey;
                             cont = true;
                         }
                     }
@@ -415,8 +451,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                     float weight = pp.st.use_mis ? pdf / (pdf + misPdf) : 1.0f;
                     L = L + background_evaluate(sc, d) * T * weight / pdf;
                 }
-                st3(w.L + 3 * slot, L);
+                if constexpr (!FIRST) st3(w.L + 3 * slot, L);
             }
+            // depth 0 starts the sample's radiance sum (the shadow rays and the later depths add to it, the film kernel reads it)
+            if constexpr (FIRST) st3(w.L + 3 * slot, L);
         }
         const uint32_t stream = ((blockIdx.x & 3u) << 2) | (((threadIdx.x >> 6) + (blockIdx.x >> 2)) & 3u);
         const uint32_t qs = stream_push(shadow, w.cnt + stream_word(kShadowCounterBase + pp.depth, stream), stream);
@@ -518,25 +556,58 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     traverse_dyn<PtMixedPolicy, kModeMixed, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, COUNT ? 0 : kShare>(sc, stk, n_closest + n_shadow, w.cnt + work_index, pol, counters, &ts);
 }
 
-// film->splat(px, py, col) for every sample of the pass, Renderer.h:745
-__global__ __launch_bounds__(kBlock) void k_film_accumulate(WfPtrs w, int filter)
+// Closest hits of the camera rays of a path-tracing pass, RTBase/Renderer.h:730-736: item k is path slot k, and its ray
+// is generated where it is fetched (Camera::generateRay through the slot's jittered sample), so a pass stores no camera
+// rays and runs no ray-generation kernel. Slots without a sample this pass are done at fetch.
+struct PtPrimaryPolicy {
+    const DeviceScene& sc; const WfPtrs& w; const CameraDev& cam; const PassParams& pp;
+    __device__ __forceinline__ bool fetch(uint32_t k, float o[3], float d[3], float& maxT) const
+    {
+        o[0] = cam.origin[0]; o[1] = cam.origin[1]; o[2] = cam.origin[2]; d[0] = d[1] = d[2] = 0.0f; maxT = 0.0f;
+        float px, py; Rng rng;
+        if (!camera_sample(w, pp, k, px, py, rng)) return false;
+        camera_ray(cam, px, py, d[0], d[1], d[2]);
+        return true;
+    }
+    __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool) const { w.hit[k] = make_hit(sc, best); }
+    __device__ __forceinline__ void note(uint32_t, uint32_t, uint32_t) const {}
+};
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_pt_closest_primary(WfPtrs w, DeviceScene sc, CameraDev cam, PassParams pp, uint32_t work_index, uint2* spill, uint32_t spill_stride,
+                                                               unsigned long long* counters)
+{
+    __shared__ unsigned long long lds[kBlock * kLdsStack];
+    LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
+    PtPrimaryPolicy pol{sc, w, cam, pp};
+    __shared__ TailShare<kBlock> ts;
+    traverse_dyn<PtPrimaryPolicy, kModeClosest, COUNT, kRefillClosest, kBlock, kLdsStack, kTriUnroll, kLeafLanesClosest, COUNT ? 0 : kShare>(sc, stk, w.P, w.cnt + work_index, pol, counters, &ts);
+}
+
+// film->splat(px, py, col) for every sample of the pass, Renderer.h:745. CAMERA: the sample is derived from the slot
+// number (path tracing, see camera_sample); otherwise ray generation has stored it.
+template <bool CAMERA>
+__global__ __launch_bounds__(kBlock) void k_film_accumulate(WfPtrs w, PassParams pp, int filter)
 {
     const uint32_t slot = global_thread();
-    if (slot >= w.P || !(w.flags[slot] & kFlagStarted)) return;
-    film_splat(w.film, (int)w.W, (int)w.H, filter, w.xy[2 * slot], w.xy[2 * slot + 1], ldc(w.L + 3 * slot));
+    float fx, fy;
+    if constexpr (CAMERA) { Rng rng; if (!camera_sample(w, pp, slot, fx, fy, rng)) return; }
+    else { if (slot >= w.P || !(w.flags[slot] & kFlagStarted)) return; fx = w.xy[2 * slot]; fy = w.xy[2 * slot + 1]; }
+    film_splat(w.film, (int)w.W, (int)w.H, filter, fx, fy, ldc(w.L + 3 * slot));
 }
 
 // Box filter (Film::splat with size 0: one pixel, weight 1, RTBase/Imaging.h:318-340): the sample of slot s lands in
 // the pixel it was generated for, unless x + r rounded up to the next integer. Phase 0 adds the samples that stay in
 // their own pixel with plain loads and stores (one sample per pixel per pass, nobody else writes it in this
 // launch); phase 1, a second launch, adds the few strays with float atomics.
-__global__ __launch_bounds__(kBlock) void k_film_accumulate_box(WfPtrs w, int phase)
+template <bool CAMERA>
+__global__ __launch_bounds__(kBlock) void k_film_accumulate_box(WfPtrs w, PassParams pp, int phase)
 {
     const uint32_t slot = global_thread();
-    if (slot >= w.P || !(w.flags[slot] & kFlagStarted)) return;
+    float fx, fy;
+    if constexpr (CAMERA) { Rng rng; if (!camera_sample(w, pp, slot, fx, fy, rng)) return; }
+    else { if (slot >= w.P || !(w.flags[slot] & kFlagStarted)) return; fx = w.xy[2 * slot]; fy = w.xy[2 * slot + 1]; }
     uint32_t tile, x, y;
     slot_pixel(w, slot, tile, x, y);
-    const float fx = w.xy[2 * slot], fy = w.xy[2 * slot + 1];
     const int px = (int)fx, py = (int)fy;
     const bool own = px == (int)x && py == (int)y;
     if (own != (phase == 0)) return;
@@ -548,12 +619,16 @@ __global__ __launch_bounds__(kBlock) void k_film_accumulate_box(WfPtrs w, int ph
     else { atomicAdd(f, v.r); atomicAdd(f + 1, v.g); atomicAdd(f + 2, v.b); }
 }
 
-inline void launch_film_accumulate(const WfPtrs& w, int filter, dim3 grid, dim3 blk, hipStream_t s)
+// camera: the samples are derived from the slot numbers (path tracing) instead of read from what ray generation stored
+inline void launch_film_accumulate(const WfPtrs& w, const PassParams& pp, bool camera, int filter, dim3 grid, dim3 blk, hipStream_t s)
 {
     if (filter == (int)RTX_FT_BOX) {
-        hipLaunchKernelGGL(k_film_accumulate_box, grid, blk, 0, s, w, 0);
-        hipLaunchKernelGGL(k_film_accumulate_box, grid, blk, 0, s, w, 1);
-    } else hipLaunchKernelGGL(k_film_accumulate, grid, blk, 0, s, w, filter);
+        for (int phase = 0; phase < 2; phase++) {
+            if (camera) hipLaunchKernelGGL(k_film_accumulate_box<true>, grid, blk, 0, s, w, pp, phase);
+            else hipLaunchKernelGGL(k_film_accumulate_box<false>, grid, blk, 0, s, w, pp, phase);
+        }
+    } else if (camera) hipLaunchKernelGGL(k_film_accumulate<true>, grid, blk, 0, s, w, pp, filter);
+    else hipLaunchKernelGGL(k_film_accumulate<false>, grid, blk, 0, s, w, pp, filter);
 }
 
 // ---- draw modes: RayTracer::direct / albedo / viewNormals, RTBase/Renderer.h:536-575 -------
@@ -1181,7 +1256,7 @@ inline int wavefront_aov(rtx_ctx* c, float* color, float* albedo, float* normal)
         hipLaunchKernelGGL(k_closest<false>, gridT, blk, 0, s, c->dscene, (const rtx_ray*)w.ray, (const uint32_t*)w.qa, 0u, (const uint32_t*)w.cnt, w.hit,
                            c->b_spill.as<uint2>(), (uint32_t)(kMaxGridBlocks * kBlock), w.cnt + kClosestWorkBase, (unsigned long long*)nullptr);
         hipLaunchKernelGGL(k_dm_shade, gridQ, blk, 0, s, w, c->dscene, pp);
-        launch_film_accumulate(w, (int)RTX_FT_BOX, gridP, blk, s);
+        launch_film_accumulate(w, pp, false, (int)RTX_FT_BOX, gridP, blk, s);
     }
     return hipGetLastError() == hipSuccess ? RTX_OK : RTX_ERR_HIP;
 }
@@ -1244,11 +1319,10 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         hipLaunchKernelGGL(k_dm_shade, gridQ, blk, 0, s, w, dscene, pp);
         shadow(s, (uint32_t)kShadowCounterBase, (uint32_t)kShadowWorkBase, spill);
         if (film_wait && hipStreamWaitEvent(s, film_wait, 0) != hipSuccess) return RTX_ERR_HIP;
-        launch_film_accumulate(w, (int)st.filter, gridP, blk, s);
+        launch_film_accumulate(w, pp, false, (int)st.filter, gridP, blk, s);
         c->stats.samples += (uint64_t)w.W * w.H;
     } else if (st.algorithm == RTX_AL_PATH_TRACE) {
-        hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, w, pp);
-        hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
+        // no ray generation: the kernels of depth 0 derive the camera samples from the slot numbers (camera_sample)
         // closest(0), shade(0), then per depth ONE traversal launch for the shadow rays of depth d - 1 and the closest
         // hits of depth d (neither depends on the other, and a traversal launch lasts at least as long as its slowest
         // ray), shade(d); the launch of depth max_bounces + 1 has the shadow rays of the last depth only.
@@ -1261,17 +1335,20 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         uint32_t* qin = w.qa; uint32_t* qout = w.qb;
         for (uint32_t d = 0; d <= st.max_bounces; d++) {
             pp.depth = d;
-            if (d == 0) closest_primary(); else mixed(d, qin);
+            if (d > 0) mixed(d, qin);
+            else if (cw) hipLaunchKernelGGL(k_pt_closest_primary<true>, gridT, blk, 0, s, w, dscene, c->dcam, pp, (uint32_t)kClosestWorkBase, spill, sstride, ctr);
+            else hipLaunchKernelGGL(k_pt_closest_primary<false>, gridT, blk, 0, s, w, dscene, c->dcam, pp, (uint32_t)kClosestWorkBase, spill, sstride, (unsigned long long*)nullptr);
             const bool regroup = d >= c->regroup_from_depth;
-            if (d == 0) { if (regroup) hipLaunchKernelGGL((k_pt_shade<true, true>), gridS, blk, 0, s, w, dscene, pp, (const uint32_t*)qin, qout);
-                          else hipLaunchKernelGGL((k_pt_shade<true, false>), gridS, blk, 0, s, w, dscene, pp, (const uint32_t*)qin, qout); }
-            else if (regroup) hipLaunchKernelGGL((k_pt_shade<false, true>), gridS, blk, 0, s, w, dscene, pp, (const uint32_t*)qin, qout);
-            else hipLaunchKernelGGL((k_pt_shade<false, false>), gridS, blk, 0, s, w, dscene, pp, (const uint32_t*)qin, qout);
+            if (d == 0) { if (regroup) hipLaunchKernelGGL((k_pt_shade<true, true>), gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
+                          else hipLaunchKernelGGL((k_pt_shade<true, false>), gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout); }
+            else if (regroup) hipLaunchKernelGGL((k_pt_shade<false, true>), gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
+            else hipLaunchKernelGGL((k_pt_shade<false, false>), gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
             std::swap(qin, qout);
         }
         mixed(st.max_bounces + 1u, qin);
         if (film_wait && hipStreamWaitEvent(s, film_wait, 0) != hipSuccess) return RTX_ERR_HIP;
-        launch_film_accumulate(w, (int)st.filter, gridP, blk, s);
+        pp.depth = 0;
+        launch_film_accumulate(w, pp, true, (int)st.filter, gridP, blk, s);
         c->stats.samples += (uint64_t)w.W * w.H;
     } else if (st.algorithm == RTX_AL_LIGHT_TRACE) {
         hipLaunchKernelGGL(k_lt_emit, gridP, blk, 0, s, w, dscene, c->dcam, pp);
@@ -1345,7 +1422,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
             hipLaunchKernelGGL(k_ir_shade, gridQ, blk, 0, s, w, dscene, v0, vb, (const uint8_t*)vis, bi == 0 ? 1 : 0, bi + 1u >= batches ? 1 : 0);
         }
         if (film_wait && hipStreamWaitEvent(s, film_wait, 0) != hipSuccess) return RTX_ERR_HIP;
-        launch_film_accumulate(w, (int)st.filter, gridP, blk, s);
+        launch_film_accumulate(w, pp, false, (int)st.filter, gridP, blk, s);
         c->stats.samples += (uint64_t)w.W * w.H;
     }
     if (hipGetLastError() != hipSuccess) return RTX_ERR_HIP;
