@@ -209,6 +209,8 @@ static int create_resources(rtx_ctx* c, int device)
         { int pc = 0; HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_closest_packet, kBlock, 0)); per_cu = std::min(per_cu, pc); }
 #endif
         c->resident_packet_blocks = std::max(1, std::min(kMaxGridBlocks, per_cu * prop.multiProcessorCount));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pt_tail, kBlock, 0));
+        c->resident_tail_blocks = std::max(1, std::min(kMaxGridBlocks, per_cu * prop.multiProcessorCount));
         if (const char* v = tuning_env("RTX_IR_PACKET")) c->ir_packet = atoi(v);
         if (const char* v = tuning_env("RTX_PRIMARY_PACKET")) c->primary_packet = atoi(v);
         if (const char* v = tuning_env("RTX_QUERY_PACKET")) c->query_packet = atoi(v);
@@ -227,6 +229,7 @@ static int create_resources(rtx_ctx* c, int device)
     if (const char* v = tuning_env("RTX_MERGE")) c->merge_shadow = atoi(v) != 0;
     if (const char* v = tuning_env("RTX_RAYS_PER_BLOCK")) c->rays_per_block = std::max(1, std::min(kBlock, atoi(v)));
     if (const char* v = tuning_env("RTX_PIPELINE")) c->pipeline = std::max(1, std::min(kPipeline, atoi(v)));
+    if (const char* v = tuning_env("RTX_TAIL_FROM")) c->tail_from_depth = (uint32_t)std::max(0, atoi(v));
     if (const char* v = tuning_env("RTX_REGROUP_FROM")) c->regroup_from_depth = (uint32_t)std::max(0, atoi(v));
     HIP_TRY(c->b_counters.ensure(4 * 5 * kWorkSlotWords));   // instrumentation counters, then the work-counter slots of the closest-hit, visibility and packet launches (+ the length of the packet kernel's rest queue)
     // RayTracer's defaults, RTBase/Settings.h:40-61
@@ -802,12 +805,16 @@ int rtx_count_render_work(rtx_ctx* c, int n_passes, uint64_t out[8])
 #ifdef RTX_TUNING
     {
         // (the instrumented passes above ran the per-lane gather; one more plain pass for the packet walk's statistics)
-        HIP_TRY(hipMemset(c->b_counters.as<unsigned long long>() + 8, 0, 6 * 8));
+        HIP_TRY(hipMemset(c->b_counters.as<unsigned long long>() + 8, 0, 16 * 8));
         int rc = wavefront_render_pass(c, 0, c->stream, nullptr, nullptr);
         if (rc) return fail(rc, "render pass failed");
         HIP_TRY(hipStreamSynchronize(c->stream));
         unsigned long long p[6];
         HIP_TRY(hipMemcpy(p, c->b_counters.as<unsigned long long>() + 8, sizeof p, hipMemcpyDeviceToHost));
+        unsigned long long ts[8];
+        HIP_TRY(hipMemcpy(ts, c->b_counters.as<unsigned long long>() + 16, sizeof ts, hipMemcpyDeviceToHost));
+        if (ts[2]) fprintf(stderr, "[rtx] tail kernel (100 MHz ticks): %llu waves with work, %.2f tasks and %.2f rounds each; per wave %.1f us in shade steps, %.1f us in traversals; longest wave %.1f us (shade %.1f, traversals %.1f)\n",
+                           ts[2], (double)ts[3] / ts[2], (double)ts[4] / ts[2], ts[0] / 100.0 / ts[2], ts[1] / 100.0 / ts[2], ts[5] / 100.0, ts[6] / 100.0, ts[7] / 100.0);
         if (p[4]) fprintf(stderr, "[rtx] packet walk: %llu packets of %.1f segments; per packet %.2f node steps with %.1f lanes, %.2f triangle steps with %.1f lanes\n", p[4], (double)p[5] / p[4],
                           (double)p[0] / p[4], p[0] ? (double)p[1] / p[0] : 0.0, (double)p[2] / p[4], p[2] ? (double)p[3] / p[2] : 0.0);
     }

@@ -81,7 +81,10 @@ __device__ __forceinline__ uint32_t nth_set_bit(unsigned long long m, uint32_t n
 
 constexpr int kModeClosest = 0, kModeAny = 1, kModeMixed = 2;
 
-template <class Policy, int MODE, bool COUNT, int REFILL, int BLOCK, int LDS_N, int TRI_UNROLL, int SCHED, int SHARE = 0>
+// LOCAL: the n items belong to the calling WAVE alone (n is wave-uniform and may differ between the waves of a workgroup;
+// `work` is not used): lanes take them in order as they fall idle, and once they are handed out the idle lanes help (SHARE).
+// The path tracer's tail kernel walks the few rays of a wave's own paths this way, depth after depth, without a launch.
+template <class Policy, int MODE, bool COUNT, int REFILL, int BLOCK, int LDS_N, int TRI_UNROLL, int SCHED, int SHARE = 0, bool LOCAL = false>
 __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BLOCK, LDS_N>& stk, uint32_t n, uint32_t* work,
                                              Policy& pol, unsigned long long* counters, TailShare<BLOCK>* ts = nullptr)
 {
@@ -114,7 +117,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
     uint32_t chunk = 64u, refill = (uint32_t)REFILL;
     constexpr uint32_t GL = 4u, GM = (1u << GL) - 1u;      // the item counters hand out groups of 16 neighbouring items
     bool spread = false, eager = false;   // eager: most lanes are free, so pending children are handed to them after every level
-    if constexpr (SHARE != 0) {
+    if constexpr (SHARE != 0 && !LOCAL) {
         const uint32_t waves = gridDim.x * (uint32_t)(BLOCK / 64);
         if ((unsigned long long)n < (unsigned long long)waves * sc.spread_below) {
             const uint32_t per = (n + waves - 1u) / waves;
@@ -130,7 +133,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
     // lanes for: one atomic per refill instead of one per chunk, but only for that last part, and nothing is parked
     // when the work runs out.
     uint32_t n_coarse = n, fine_range = 0;             // items [0, n_coarse) go out in chunks; every counter then has fine_range positions of the rest
-    if (!spread && sc.fine_per_wave && n <= 0xFFFF0000u) {      // (beyond that the 32-bit item arithmetic below could wrap)
+    if (!LOCAL && !spread && sc.fine_per_wave && n <= 0xFFFF0000u) {      // (beyond that the 32-bit item arithmetic below could wrap)
         const unsigned long long want = (unsigned long long)gridDim.x * (uint32_t)(BLOCK / 64) * sc.fine_per_wave;
         n_coarse = want >= n ? 0u : (uint32_t)((n - want) / 64u) * 64u;
         fine_range = ((n - n_coarse + ((uint32_t)kWorkSegments << GL) - 1u) / ((uint32_t)kWorkSegments << GL)) << GL;
@@ -141,8 +144,11 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
     bool exhausted = false, fine = n_coarse == 0u && fine_range != 0u;
     // counters of the current part that are known to be dry: those that never had a chunk, then what this wave finds out
     unsigned long long dry_seen = fine ? 0ull : ~__ballot(work_chunk(0u, lane) < n_chunks);
-    if (!fine && dry_seen == ~0ull) { if (fine_range != 0u) { fine = true; dry_seen = 0ull; } else exhausted = true; }
-    if (!fine && !exhausted && ((dry_seen >> seg) & 1ull)) seg = nth_set_bit(~dry_seen, (hop >> 16) % (uint32_t)__popcll(~dry_seen));   // (a launch of a few chunks)
+    if constexpr (LOCAL) { loc_end = n; exhausted = n == 0u; }
+    else {
+        if (!fine && dry_seen == ~0ull) { if (fine_range != 0u) { fine = true; dry_seen = 0ull; } else exhausted = true; }
+        if (!fine && !exhausted && ((dry_seen >> seg) & 1ull)) seg = nth_set_bit(~dry_seen, (hop >> 16) % (uint32_t)__popcll(~dry_seen));   // (a launch of a few chunks)
+    }
     for (;;) {
         if constexpr (SHARE) {
             if (tail && item != kNone) {
@@ -179,6 +185,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
         unsigned long long m = __ballot(cur == kDone && item == kNone);
         uint32_t n_idle = (uint32_t)__popcll(m);
         while (!exhausted && n_idle >= refill) {
+            if (LOCAL && loc_next == loc_end) { exhausted = true; break; }
             if (loc_next == loc_end) {
                 const uint32_t ask = fine ? n_idle : 1u;
                 uint32_t j = 0;

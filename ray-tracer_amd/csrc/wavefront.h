@@ -18,6 +18,13 @@
 #include "trace_kernels.h"
 #include "traverse_packet.h"
 
+// statistics of the tuning build (librtx_tuning.so): extra kernel arguments and the code that fills them
+#ifdef RTX_TUNING
+#define RTX_PACKET_STATS(...) __VA_ARGS__
+#else
+#define RTX_PACKET_STATS(...)
+#endif
+
 namespace rtx {
 
 constexpr uint32_t kFlagCanHitLight = 1u;   // emission counts at the next hit (Renderer.h:487,516)
@@ -362,6 +369,74 @@ __device__ __forceinline__ bool regroup_by_class(ShadeRegroup& s, bool active, u
     return mine;
 }
 
+// What shading one path leaves for the queues: whether it goes on (its new ray and state are in the slot) and whether
+// it asks for a shadow ray (segment sx -> p2, value sval the path gains if the segment is free).
+struct ShadeOut { bool cont, shadow; V3 sx, p2; C3 sval; };
+// One depth of RayTracer::pathTrace, RTBase/Renderer.h:476-526, for the path in `slot` whose ray found hit `h`.
+// FIRST: depth 0, the path's state is the camera sample of the slot (nothing stored yet).
+template <bool FIRST>
+__device__ __forceinline__ void pt_shade_item(const WfPtrs& w, const DeviceScene& sc, const CameraDev& cam, const PassParams& pp, uint32_t slot, const rtx_hit& h, ShadeOut& out)
+{
+    bool& cont = out.cont; bool& shadow = out.shadow; V3& p2 = out.p2; C3& sval = out.sval; V3& sx = out.sx;
+    cont = false; shadow = false;
+    V3 o, d; C3 T, L; uint32_t flags, rkey, rdim; float misPdf;
+    if constexpr (FIRST) {
+        // the state ray generation would have stored (Renderer.h:730-736): the camera ray of the slot's sample, unit
+        // throughput, no radiance yet, the generator behind the two jitter draws
+        float px, py; Rng crng;
+        camera_sample(w, pp, slot, px, py, crng);
+        float dx, dy, dz; camera_ray(cam, px, py, dx, dy, dz);
+        o = ld3(cam.origin); d = mk(dx, dy, dz);
+        T = mkc(1.0f, 1.0f, 1.0f); L = mkc(0.0f, 0.0f, 0.0f);
+        flags = kFlagStarted | (pp.st.can_hit_light ? kFlagCanHitLight : 0u); misPdf = 0.0f; rkey = crng.key; rdim = crng.dim;
+    } else {
+        const rtx_ray r = w.ray[slot];
+        T = ldc(w.T + 3 * slot); L = ldc(w.L + 3 * slot);
+        flags = w.flags[slot]; misPdf = w.mis[slot];
+        rkey = w.key[slot]; rdim = w.dim[slot];
+        // the whole path state in one round trip: without this the compiler loads each piece where it is first
+        // read, behind the triangle record, the material and the texture, one dependent round trip each
+        asm volatile("" :: "v"(T.r), "v"(T.g), "v"(T.b), "v"(L.r), "v"(L.g), "v"(L.b), "v"(flags), "v"(misPdf), "v"(rkey), "v"(rdim));
+        o = ld3(r.o); d = ld3(r.d);
+    }
+    if (h.t < FLT_MAX) {
+        Shading sd; shading_data(sc, h, o, d, sd);
+        if (sd.mat->is_light) {
+            if (flags & kFlagCanHitLight) { L = L + T * ldc(sd.mat->emission); if constexpr (!FIRST) st3(w.L + 3 * slot, L); }
+        } else {
+            Rng rng; rng.key = rkey; rng.dim = rdim;
+            C3 dv;
+            if (direct_request(sc, sd, rng, pp.st.use_mis != 0, misPdf, p2, dv)) { shadow = true; sval = T * dv; sx = sd.x; }
+            if (pp.depth < pp.st.max_bounces) {
+                float rr = wmin(lum(T), 0.9f);
+                if (!(rr < rng.next())) {
+                    T = T / rr;
+                    C3 bs; float pdf; V3 wi = bsdf_sample(sc, sd, rng, bs, pdf);
+                    T = T * bs * fabsf(dot(wi, sd.sNormal)) / pdf;
+                    V3 no = sd.x + (wi * kEps);
+                    rtx_ray nr; nr.o[0] = no.x; nr.o[1] = no.y; nr.o[2] = no.z; nr.d[0] = wi.x; nr.d[1] = wi.y; nr.d[2] = wi.z;
+                    w.ray[slot] = nr; st3(w.T + 3 * slot, T); w.mis[slot] = pdf;
+                    w.flags[slot] = (flags & ~kFlagCanHitLight) | (isPureSpecular(*sd.mat) ? kFlagCanHitLight : 0u);
+                    if constexpr (FIRST) w.key[slot] = rkey;
+                    cont = true;
+                }
+            }
+            w.dim[slot] = rng.dim;
+        }
+    } else {
+        // Renderer.h:519-525
+        if (pp.depth == 0) L = L + background_evaluate(sc, d);
+        else {
+            float pdf = background_pdf(sc, d);
+            float weight = pp.st.use_mis ? pdf / (pdf + misPdf) : 1.0f;
+            L = L + background_evaluate(sc, d) * T * weight / pdf;
+        }
+        if constexpr (!FIRST) st3(w.L + 3 * slot, L);
+    }
+    // depth 0 starts the sample's radiance sum (the shadow rays and the later depths add to it, the film kernel reads it)
+    if constexpr (FIRST) st3(w.L + 3 * slot, L);
+}
+
 // One depth of RayTracer::pathTrace, RTBase/Renderer.h:476-526, for every live path: one queue position per thread.
 // FIRST: the queue of camera samples (dense, its length in the queue word of depth 0); otherwise a streamed queue.
 // REGROUP: the workgroup sorts its items by class first (camera rays arrive in pixel-block order and are coherent as
@@ -398,64 +473,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             if (have && h.t < FLT_MAX) cls = sc.shade[h.id].shade_class;
             have = regroup_by_class(s_regroup, have, cls, slot, h);
         }
-        if (have) {
-            V3 o, d; C3 T, L; uint32_t flags, rkey, rdim; float misPdf;
-            if constexpr (FIRST) {
-                // the state ray generation would have stored (Renderer.h:730-736): the camera ray of the slot's sample, unit
-                // throughput, no radiance yet, the generator behind the two jitter draws
-                float px, py; Rng crng;
-                camera_sample(w, pp, slot, px, py, crng);
-                float dx, dy, dz; camera_ray(cam, px, py, dx, dy, dz);
-                o = ld3(cam.origin); d = mk(dx, dy, dz);
-                T = mkc(1.0f, 1.0f, 1.0f); L = mkc(0.0f, 0.0f, 0.0f);
-                flags = kFlagStarted | (pp.st.can_hit_light ? kFlagCanHitLight : 0u); misPdf = 0.0f; rkey = crng.key; rdim = crng.dim;
-            } else {
-                const rtx_ray r = w.ray[slot];
-                T = ldc(w.T + 3 * slot); L = ldc(w.L + 3 * slot);
-                flags = w.flags[slot]; misPdf = w.mis[slot];
-                rkey = w.key[slot]; rdim = w.dim[slot];
-                // the whole path state in one round trip: without this the compiler loads each piece where it is first
-                // read, behind the triangle record, the material and the texture, one dependent round trip each
-                asm volatile("" :: "v"(T.r), "v"(T.g), "v"(T.b), "v"(L.r), "v"(L.g), "v"(L.b), "v"(flags), "v"(misPdf), "v"(rkey), "v"(rdim));
-                o = ld3(r.o); d = ld3(r.d);
-            }
-            if (h.t < FLT_MAX) {
-                Shading sd; shading_data(sc, h, o, d, sd);
-                if (sd.mat->is_light) {
-                    if (flags & kFlagCanHitLight) { L = L + T * ldc(sd.mat->emission); if constexpr (!FIRST) st3(w.L + 3 * slot, L); }
-                } else {
-                    Rng rng; rng.key = rkey; rng.dim = rdim;
-                    C3 dv;
-                    if (direct_request(sc, sd, rng, pp.st.use_mis != 0, misPdf, p2, dv)) { shadow = true; sval = T * dv; sx = sd.x; }
-                    if (pp.depth < pp.st.max_bounces) {
-                        float rr = wmin(lum(T), 0.9f);
-                        if (!(rr < rng.next())) {
-                            T = T / rr;
-                            C3 bs; float pdf; V3 wi = bsdf_sample(sc, sd, rng, bs, pdf);
-                            T = T * bs * fabsf(dot(wi, sd.sNormal)) / pdf;
-                            V3 no = sd.x + (wi * kEps);
-                            rtx_ray nr; nr.o[0] = no.x; nr.o[1] = no.y; nr.o[2] = no.z; nr.d[0] = wi.x; nr.d[1] = wi.y; nr.d[2] = wi.z;
-                            w.ray[slot] = nr; st3(w.T + 3 * slot, T); w.mis[slot] = pdf;
-                            w.flags[slot] = (flags & ~kFlagCanHitLight) | (isPureSpecular(*sd.mat) ? kFlagCanHitLight : 0u);
-                            if constexpr (FIRST) w.key[slot] = rkey;
-                            cont = true;
-                        }
-                    }
-                    w.dim[slot] = rng.dim;
-                }
-            } else {
-                // Renderer.h:519-525
-                if (pp.depth == 0) L = L + background_evaluate(sc, d);
-                else {
-                    float pdf = background_pdf(sc, d);
-                    float weight = pp.st.use_mis ? pdf / (pdf + misPdf) : 1.0f;
-                    L = L + background_evaluate(sc, d) * T * weight / pdf;
-                }
-                if constexpr (!FIRST) st3(w.L + 3 * slot, L);
-            }
-            // depth 0 starts the sample's radiance sum (the shadow rays and the later depths add to it, the film kernel reads it)
-            if constexpr (FIRST) st3(w.L + 3 * slot, L);
-        }
+        ShadeOut so; so.cont = so.shadow = false; so.sx = so.p2 = mk(0, 0, 0); so.sval = mkc(0, 0, 0);
+        if (have) pt_shade_item<FIRST>(w, sc, cam, pp, slot, h, so);
+        cont = so.cont; shadow = so.shadow; p2 = so.p2; sval = so.sval; sx = so.sx;
         const uint32_t stream = ((blockIdx.x & 3u) << 2) | (((threadIdx.x >> 6) + (blockIdx.x >> 2)) & 3u);
         const uint32_t qs = stream_push(shadow, w.cnt + stream_word(kShadowCounterBase + pp.depth, stream), stream);
         if (shadow) {
@@ -556,9 +576,107 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     traverse_dyn<PtMixedPolicy, kModeMixed, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, COUNT ? 0 : kShare>(sc, stk, n_closest + n_shadow, w.cnt + work_index, pol, counters, &ts);
 }
 
+// The late depths of a path-tracing pass in ONE launch. Behind the second bounce a 1080p pass holds a few percent of
+// its paths, and as a wavefront every depth still costs a traversal launch that lasts as long as its slowest ray plus a
+// shade launch that lasts as long as its chain of dependent loads: ~350 us for 3 % of the rays. Here a WAVE takes a
+// block of 64 positions of the live queue of depth pp.depth (their closest hits are known) and carries those paths to
+// their ends by itself: shade, then one wave-local traversal for the shadow rays just asked for and the next rays of the
+// survivors (traverse_dyn's LOCAL mode; idle lanes help the busy ones), shade again, ... No queue leaves the wave:
+// the lists (live slots, their hits, pending shadow segments) sit in LDS, the path state stays in the slot arrays.
+// Every sum is taken in the order the wavefront kernels take it (a path's shadow ray of depth d before its emission at
+// depth d + 1), so the film is the same bit for bit whichever way the late depths run.
+struct TailWaveLists {
+    uint32_t live[64];                                                 // path slots that go on, in list order
+    uint32_t hit_id[64]; float hit_t[64], hit_alpha[64], hit_beta[64], hit_gamma[64];   // closest hit of live[k]
+    float seg[6][64], val[3][64]; uint32_t seg_slot[64];               // shadow rays asked for by the last shade step
+};
+struct PtTailPolicy {
+    const DeviceScene& sc; const WfPtrs& w; TailWaveLists& t; uint32_t n_live;
+    __device__ __forceinline__ bool fetch(uint32_t k, float o[3], float d[3], float& maxT, bool& any) const
+    {
+        if (k < n_live) {
+            const rtx_ray r = w.ray[t.live[k]];
+            o[0] = r.o[0]; o[1] = r.o[1]; o[2] = r.o[2]; d[0] = r.d[0]; d[1] = r.d[1]; d[2] = r.d[2]; maxT = 0.0f; any = false;
+        } else {
+            const uint32_t j = k - n_live;
+            const float sg[6] = {t.seg[0][j], t.seg[1][j], t.seg[2][j], t.seg[3][j], t.seg[4][j], t.seg[5][j]};
+            segment_to_ray(sg, o, d, maxT); any = true;
+        }
+        return true;
+    }
+    __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool reached) const
+    {
+        if (k < n_live) {
+            const rtx_hit h = make_hit(sc, best);
+            t.hit_id[k] = h.id; t.hit_t[k] = h.t; t.hit_alpha[k] = h.alpha; t.hit_beta[k] = h.beta; t.hit_gamma[k] = h.gamma;
+        } else if (reached && best.pos == 0xFFFFFFFFu) {
+            const uint32_t j = k - n_live, slot = t.seg_slot[j];
+            C3 L = ldc(w.L + 3 * slot) + mkc(t.val[0][j], t.val[1][j], t.val[2][j]);
+            st3(w.L + 3 * slot, L);
+        }
+    }
+    __device__ __forceinline__ void note(uint32_t, uint32_t, uint32_t) const {}
+};
+constexpr int kTailRefill = 8;       // idle lanes at which a wave takes more of its own items
+__global__ __launch_bounds__(kBlock) void k_pt_tail(WfPtrs w, DeviceScene sc, CameraDev cam, PassParams pp, const uint32_t* __restrict__ qin, uint32_t task_index,
+                                                    uint2* spill, uint32_t spill_stride RTX_PACKET_STATS(, unsigned long long* stats))
+{
+    RTX_PACKET_STATS(unsigned long long t_shade = 0, t_trace = 0, t_begin = wall_clock64(); uint32_t n_rounds = 0, n_tasks_done = 0;)
+    __shared__ unsigned long long lds[kBlock * kLdsStack];
+    __shared__ TailShare<kBlock> ts;
+    __shared__ StreamLens s_in;
+    __shared__ TailWaveLists s_lists[kBlock / 64];
+    LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
+    const uint32_t first_depth = pp.depth;
+    const uint32_t n_tasks = stream_load(w.cnt, first_depth, s_in) >> 6;       // (the only barrier: from here on the waves go their own ways)
+    TailWaveLists& t = s_lists[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (;;) {
+        uint32_t task = 0;
+        if (lane == 0) task = atomicAdd(w.cnt + task_index, 1u);
+        task = (uint32_t)__builtin_amdgcn_readfirstlane((int)task);
+        if (task >= n_tasks) break;
+        const uint32_t i = task * 64u + lane;
+        bool have = stream_valid(s_in, i);
+        uint32_t slot = 0; rtx_hit h; h.id = 0; h.t = FLT_MAX; h.alpha = h.beta = h.gamma = 0.0f;
+        if (have) { slot = qin[i]; h = w.hit[slot]; }
+        for (pp.depth = first_depth; ; pp.depth++) {
+            ShadeOut so; so.cont = so.shadow = false; so.sx = so.p2 = mk(0, 0, 0); so.sval = mkc(0, 0, 0);
+            RTX_PACKET_STATS(const unsigned long long c0 = wall_clock64();)
+            if (have) pt_shade_item<false>(w, sc, cam, pp, slot, h, so);
+            const unsigned long long mc = __ballot(so.cont), ms = __ballot(so.shadow);
+            RTX_PACKET_STATS(t_shade += wall_clock64() - c0; n_rounds++;)
+            const uint32_t n_live = (uint32_t)__popcll(mc), n_seg = (uint32_t)__popcll(ms);
+            if (n_live + n_seg == 0u) break;
+            if (so.cont) t.live[__popcll(mc & below)] = slot;
+            if (so.shadow) {
+                const uint32_t j = (uint32_t)__popcll(ms & below);
+                t.seg[0][j] = so.sx.x; t.seg[1][j] = so.sx.y; t.seg[2][j] = so.sx.z; t.seg[3][j] = so.p2.x; t.seg[4][j] = so.p2.y; t.seg[5][j] = so.p2.z;
+                t.val[0][j] = so.sval.r; t.val[1][j] = so.sval.g; t.val[2][j] = so.sval.b; t.seg_slot[j] = slot;
+            }
+            // the lists and the slots' new state were written by other lanes than the ones that read them next
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            PtTailPolicy pol{sc, w, t, n_live};
+            RTX_PACKET_STATS(const unsigned long long c1 = wall_clock64();)
+            traverse_dyn<PtTailPolicy, kModeMixed, false, kTailRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare, true>(sc, stk, n_live + n_seg, nullptr, pol, nullptr, &ts);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            RTX_PACKET_STATS(t_trace += wall_clock64() - c1;)
+            if (n_live == 0u) break;                                   // the shadow rays of the paths' last vertices
+            have = lane < n_live;
+            if (have) { slot = t.live[lane]; h.id = t.hit_id[lane]; h.t = t.hit_t[lane]; h.alpha = t.hit_alpha[lane]; h.beta = t.hit_beta[lane]; h.gamma = t.hit_gamma[lane]; }
+        }
+        RTX_PACKET_STATS(n_tasks_done++;)
+    }
+    // (tuning build: clock ticks per wave in shade steps and in traversals, waves with a task, their tasks and rounds, the longest wave)
+    RTX_PACKET_STATS(if (stats && lane == 0 && n_tasks_done) { atomicAdd(&stats[16], t_shade); atomicAdd(&stats[17], t_trace); atomicAdd(&stats[18], 1ull); atomicAdd(&stats[19], (unsigned long long)n_tasks_done);
+                     atomicAdd(&stats[20], (unsigned long long)n_rounds); atomicMax(&stats[21], wall_clock64() - t_begin); atomicMax(&stats[22], t_shade); atomicMax(&stats[23], t_trace); })
+}
+
 // Closest hits of the camera rays of a path-tracing pass, RTBase/Renderer.h:730-736: item k is path slot k, and its ray
 // is generated where it is fetched (Camera::generateRay through the slot's jittered sample), so a pass stores no camera
 // rays and runs no ray-generation kernel. Slots without a sample this pass are done at fetch.
+template <bool COUNT>
 struct PtPrimaryPolicy {
     const DeviceScene& sc; const WfPtrs& w; const CameraDev& cam; const PassParams& pp;
     __device__ __forceinline__ bool fetch(uint32_t k, float o[3], float d[3], float& maxT) const
@@ -567,20 +685,23 @@ struct PtPrimaryPolicy {
         float px, py; Rng rng;
         if (!camera_sample(w, pp, k, px, py, rng)) return false;
         camera_ray(cam, px, py, d[0], d[1], d[2]);
+        // instrumented runs: the number of camera rays, kept where a dense queue of depth 0 would keep its length
+        if constexpr (COUNT) atomicAdd(&w.cnt[(0) * kQueueStride], 1u);
         return true;
     }
     __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool) const { w.hit[k] = make_hit(sc, best); }
     __device__ __forceinline__ void note(uint32_t, uint32_t, uint32_t) const {}
 };
+// (held to the registers that keep five waves per SIMD, like the other traversal kernels: the ray set-up at fetch would take 106)
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_pt_closest_primary(WfPtrs w, DeviceScene sc, CameraDev cam, PassParams pp, uint32_t work_index, uint2* spill, uint32_t spill_stride,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_pt_closest_primary(WfPtrs w, DeviceScene sc, CameraDev cam, PassParams pp, uint32_t work_index, uint2* spill, uint32_t spill_stride,
                                                                unsigned long long* counters)
 {
     __shared__ unsigned long long lds[kBlock * kLdsStack];
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
-    PtPrimaryPolicy pol{sc, w, cam, pp};
+    PtPrimaryPolicy<COUNT> pol{sc, w, cam, pp};
     __shared__ TailShare<kBlock> ts;
-    traverse_dyn<PtPrimaryPolicy, kModeClosest, COUNT, kRefillClosest, kBlock, kLdsStack, kTriUnroll, kLeafLanesClosest, COUNT ? 0 : kShare>(sc, stk, w.P, w.cnt + work_index, pol, counters, &ts);
+    traverse_dyn<PtPrimaryPolicy<COUNT>, kModeClosest, COUNT, kRefillClosest, kBlock, kLdsStack, kTriUnroll, kLeafLanesClosest, COUNT ? 0 : kShare>(sc, stk, w.P, w.cnt + work_index, pol, counters, &ts);
 }
 
 // film->splat(px, py, col) for every sample of the pass, Renderer.h:745. CAMERA: the sample is derived from the slot
@@ -1018,11 +1139,6 @@ __global__ __launch_bounds__(kBlock) void k_ir_trace(WfPtrs w, DeviceScene sc, u
 // sweeps the pairs on one front), evaluates the geometry term of 64 pairs at a time, marks the culled ones done and
 // collects the others in a small ring in LDS; whenever the ring holds a full wave of segments (or the pairs have
 // run out) it walks them as one packet. Same result bytes as k_ir_trace.
-#ifdef RTX_TUNING
-#define RTX_PACKET_STATS(...) __VA_ARGS__
-#else
-#define RTX_PACKET_STATS(...)
-#endif
 __global__ __launch_bounds__(kBlock) void k_ir_trace_packet(WfPtrs w, DeviceScene sc, uint32_t v0, uint32_t vb, uint8_t* vis, uint32_t work_index, uint2* spill, uint32_t spill_stride
                                                             RTX_PACKET_STATS(, unsigned long long* stats))
 {
@@ -1333,8 +1449,17 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
             else hipLaunchKernelGGL(k_pt_trace_mixed<false>, gridT, blk, 0, s, w, dscene, d, queue, (uint32_t)(kClosestWorkBase + d * kWorkSlotWords), spill, sstride, (unsigned long long*)nullptr);
         };
         uint32_t* qin = w.qa; uint32_t* qout = w.qb;
+        // from depth c->tail_from_depth on (few paths left) one launch walks the rest of every path, see k_pt_tail
+        const uint32_t tail_from = (cw || c->tail_from_depth == 0u) ? 0xFFFFFFFFu : c->tail_from_depth;
+        bool tail_done = false;
         for (uint32_t d = 0; d <= st.max_bounces; d++) {
             pp.depth = d;
+            if (d >= tail_from) {
+                mixed(d, qin);
+                hipLaunchKernelGGL(k_pt_tail, dim3(c->resident_tail_blocks), blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, (uint32_t)kShadowWorkBase, spill, sstride RTX_PACKET_STATS(, c->b_counters.as<unsigned long long>()));
+                tail_done = true;
+                break;
+            }
             if (d > 0) mixed(d, qin);
             else if (cw) hipLaunchKernelGGL(k_pt_closest_primary<true>, gridT, blk, 0, s, w, dscene, c->dcam, pp, (uint32_t)kClosestWorkBase, spill, sstride, ctr);
             else hipLaunchKernelGGL(k_pt_closest_primary<false>, gridT, blk, 0, s, w, dscene, c->dcam, pp, (uint32_t)kClosestWorkBase, spill, sstride, (unsigned long long*)nullptr);
@@ -1345,7 +1470,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
             else hipLaunchKernelGGL((k_pt_shade<false, false>), gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
             std::swap(qin, qout);
         }
-        mixed(st.max_bounces + 1u, qin);
+        if (!tail_done) mixed(st.max_bounces + 1u, qin);
         if (film_wait && hipStreamWaitEvent(s, film_wait, 0) != hipSuccess) return RTX_ERR_HIP;
         pp.depth = 0;
         launch_film_accumulate(w, pp, true, (int)st.filter, gridP, blk, s);
