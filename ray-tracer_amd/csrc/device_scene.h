@@ -90,7 +90,6 @@ struct DeviceScene {
     float env_inv_w, env_inv_h;
     float scene_centre[3], scene_radius;   // SceneBounds, SceneLoader.h:387-388
     uint32_t fine_per_wave;      // the last fine_per_wave items per wave of the grid are handed out item by item instead of in chunks (traverse_dyn.h); 0: none
-    uint32_t local_eager_below;  // a wave-local traversal (LOCAL mode) of at most this many rays descends one level per trip, so that the children just pushed go to free lanes at once
     uint32_t spread_below;       // launches with fewer items per wave of the grid than this are spread thin (traverse_dyn.h); 0: never
 };
 

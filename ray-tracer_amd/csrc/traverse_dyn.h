@@ -144,7 +144,7 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
     bool exhausted = false, fine = n_coarse == 0u && fine_range != 0u;
     // counters of the current part that are known to be dry: those that never had a chunk, then what this wave finds out
     unsigned long long dry_seen = fine ? 0ull : ~__ballot(work_chunk(0u, lane) < n_chunks);
-    if constexpr (LOCAL) { loc_end = n; exhausted = n == 0u; eager = n <= sc.local_eager_below; }
+    if constexpr (LOCAL) { loc_end = n; exhausted = n == 0u; }
     else {
         if (!fine && dry_seen == ~0ull) { if (fine_range != 0u) { fine = true; dry_seen = 0ull; } else exhausted = true; }
         if (!fine && !exhausted && ((dry_seen >> seg) & 1ull)) seg = nth_set_bit(~dry_seen, (hop >> 16) % (uint32_t)__popcll(~dry_seen));   // (a launch of a few chunks)
