@@ -621,7 +621,7 @@ constexpr int kTailRefill = 8;       // idle lanes at which a wave takes more of
 __global__ __launch_bounds__(kBlock) void k_pt_tail(WfPtrs w, DeviceScene sc, CameraDev cam, PassParams pp, const uint32_t* __restrict__ qin, uint32_t task_index,
                                                     uint2* spill, uint32_t spill_stride RTX_PACKET_STATS(, unsigned long long* stats))
 {
-    RTX_PACKET_STATS(unsigned long long t_shade = 0, t_trace = 0, t_begin = wall_clock64(); uint32_t n_rounds = 0, n_tasks_done = 0;)
+    RTX_PACKET_STATS(unsigned long long t_shade = 0, t_trace = 0, t_begin = stats ? wall_clock64() : 0ull; uint32_t n_rounds = 0, n_tasks_done = 0;)
     __shared__ unsigned long long lds[kBlock * kLdsStack];
     __shared__ TailShare<kBlock> ts;
     __shared__ StreamLens s_in;
@@ -643,10 +643,10 @@ __global__ __launch_bounds__(kBlock) void k_pt_tail(WfPtrs w, DeviceScene sc, Ca
         if (have) { slot = qin[i]; h = w.hit[slot]; }
         for (pp.depth = first_depth; ; pp.depth++) {
             ShadeOut so; so.cont = so.shadow = false; so.sx = so.p2 = mk(0, 0, 0); so.sval = mkc(0, 0, 0);
-            RTX_PACKET_STATS(const unsigned long long c0 = wall_clock64();)
+            RTX_PACKET_STATS(const unsigned long long c0 = stats ? wall_clock64() : 0ull;)
             if (have) pt_shade_item<false>(w, sc, cam, pp, slot, h, so);
             const unsigned long long mc = __ballot(so.cont), ms = __ballot(so.shadow);
-            RTX_PACKET_STATS(t_shade += wall_clock64() - c0; n_rounds++;)
+            RTX_PACKET_STATS(if (stats) { t_shade += wall_clock64() - c0; n_rounds++; })
             const uint32_t n_live = (uint32_t)__popcll(mc), n_seg = (uint32_t)__popcll(ms);
             if (n_live + n_seg == 0u) break;
             if (so.cont) t.live[__popcll(mc & below)] = slot;
@@ -658,10 +658,10 @@ __global__ __launch_bounds__(kBlock) void k_pt_tail(WfPtrs w, DeviceScene sc, Ca
             // the lists and the slots' new state were written by other lanes than the ones that read them next
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             PtTailPolicy pol{sc, w, t, n_live};
-            RTX_PACKET_STATS(const unsigned long long c1 = wall_clock64();)
+            RTX_PACKET_STATS(const unsigned long long c1 = stats ? wall_clock64() : 0ull;)
             traverse_dyn<PtTailPolicy, kModeMixed, false, kTailRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare, true>(sc, stk, n_live + n_seg, nullptr, pol, nullptr, &ts);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            RTX_PACKET_STATS(t_trace += wall_clock64() - c1;)
+            RTX_PACKET_STATS(if (stats) t_trace += wall_clock64() - c1;)
             if (n_live == 0u) break;                                   // the shadow rays of the paths' last vertices
             have = lane < n_live;
             if (have) { slot = t.live[lane]; h.id = t.hit_id[lane]; h.t = t.hit_t[lane]; h.alpha = t.hit_alpha[lane]; h.beta = t.hit_beta[lane]; h.gamma = t.hit_gamma[lane]; }
@@ -1456,7 +1456,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
             pp.depth = d;
             if (d >= tail_from) {
                 mixed(d, qin);
-                hipLaunchKernelGGL(k_pt_tail, dim3(c->resident_tail_blocks), blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, (uint32_t)kShadowWorkBase, spill, sstride RTX_PACKET_STATS(, c->b_counters.as<unsigned long long>()));
+                hipLaunchKernelGGL(k_pt_tail, dim3(c->resident_tail_blocks), blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, (uint32_t)kShadowWorkBase, spill, sstride RTX_PACKET_STATS(, c->tail_stats ? c->b_counters.as<unsigned long long>() : nullptr));
                 tail_done = true;
                 break;
             }
