@@ -87,7 +87,8 @@ struct rtx_ctx {
     uint32_t tiles_x = 0, tiles_y = 0;
     rtx::WavefrontBuffers* wf[rtx::kPipeline] = {};   // path state of the passes in flight; [0] always exists once a camera is set
     int pipeline = 3;                                  // passes rtx_render_passes keeps in flight (RTX_PIPELINE); 3 + the caller's stream fit the 4 hardware queues
-    uint32_t tail_from_depth = 2;                      // path tracing: from this depth on one launch carries every path to its end (k_pt_tail); 0: never (RTX_TAIL_FROM)
+    uint32_t tail_from_depth = 1;                      // path tracing: not before this depth one launch carries every path to its end (k_pt_tail); 0: never (RTX_TAIL_FROM)
+    uint32_t* depth_stats = nullptr;                   // pinned host memory the path tracer's last kernel reports its queue sizes per depth to (see publish_depth_stats)
     bool tail_stats = false;                           // (tuning build, RTX_DEBUG_COUNTERS) the tail kernel times its phases
     int resident_tail_blocks = 256;                    // workgroups of that kernel the device holds at once
     uint32_t regroup_from_depth = 1;                   // path tracing: the shade kernels from this depth on sort their items by class inside the workgroup (RTX_REGROUP_FROM)

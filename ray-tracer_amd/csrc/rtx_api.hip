@@ -232,6 +232,8 @@ static int create_resources(rtx_ctx* c, int device)
     c->tail_stats = tuning_env("RTX_DEBUG_COUNTERS") != nullptr;
     if (const char* v = tuning_env("RTX_TAIL_FROM")) c->tail_from_depth = (uint32_t)std::max(0, atoi(v));
     if (const char* v = tuning_env("RTX_REGROUP_FROM")) c->regroup_from_depth = (uint32_t)std::max(0, atoi(v));
+    HIP_TRY(hipHostMalloc((void**)&c->depth_stats, 96 * sizeof(uint32_t), hipHostMallocDefault));
+    for (int i = 0; i < 96; i++) c->depth_stats[i] = 0xFFFFFFFFu;
     HIP_TRY(c->b_counters.ensure(4 * 5 * kWorkSlotWords));   // instrumentation counters, then the work-counter slots of the closest-hit, visibility and packet launches (+ the length of the packet kernel's rest queue)
     // RayTracer's defaults, RTBase/Settings.h:40-61
     rtx_settings& s = c->settings;
@@ -259,9 +261,13 @@ void rtx_destroy(rtx_ctx* c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->depth_stats) (void)hipHostFree(c->depth_stats);
     delete c;
     context_gone();
 }
+
+// new scene, camera or settings: what the last passes reported about their queue sizes says nothing about the next ones
+static void forget_depth_stats(rtx_ctx* c) { if (c->depth_stats) for (int i = 0; i < 96; i++) c->depth_stats[i] = 0xFFFFFFFFu; }
 
 int rtx_set_stream(rtx_ctx* c, void* s)
 {
@@ -279,6 +285,7 @@ int rtx_upload_scene(rtx_ctx* c, const rtx_scene_desc* d)
     if (!d) return fail(RTX_ERR_INVALID, "scene is null");
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_scene = false;
+    forget_depth_stats(c);
     // the BVH is built on the device unless RTX_BVH_BUILD=host asks for the host build (same tree)
     const char* where = getenv("RTX_BVH_BUILD");
     Bvh2BuildFn device_build = [c](const std::vector<TriPrep>& t, const float* mn, const float* mx, Bvh2& out) {
@@ -358,6 +365,7 @@ int rtx_set_camera(rtx_ctx* c, const rtx_camera* cam)
     if (!cam) return fail(RTX_ERR_INVALID, "camera is null");
     if (cam->width < 1 || cam->height < 1 || (uint64_t)cam->width * cam->height > (1ull << 28)) return fail(RTX_ERR_INVALID, "bad film size %dx%d", cam->width, cam->height);
     HIP_TRY(hipStreamSynchronize(c->stream));
+    forget_depth_stats(c);
     bool resized = !c->have_camera || cam->width != c->cam.width || cam->height != c->cam.height;
     c->cam = *cam;
     CameraDev& d = c->dcam;
@@ -387,6 +395,7 @@ int rtx_set_settings(rtx_ctx* c, const rtx_settings* s)
         return fail(RTX_ERR_INVALID, "bad shard (mode %d rank %d world %d)", s->shard_mode, s->shard_rank, s->shard_world);
     if (s->max_bounces > 64) return fail(RTX_ERR_INVALID, "max_bounces %u too large", s->max_bounces);
     c->settings = *s;
+    forget_depth_stats(c);
     // RayTracer::init, RTBase/Renderer.h:81-84
     c->settings.adaptive_sampling = s->adaptive_sampling && s->algorithm == RTX_AL_PATH_TRACE;
     if (!c->settings.adaptive_sampling) c->settings.init_spp = s->total_spp;

@@ -67,6 +67,7 @@ struct WfPtrs {
     // Path slots exist for the tiles this context renders only: local tile l = slot / 256 is film tile l * tile_mul + tile_add
     // (every tile, mul 1 add 0, unless the tiles are split over GPUs: then the tiles t % world == rank, mul = world, add = rank)
     uint32_t tile_mul, tile_add, n_local_tiles;
+    uint32_t* depth_stats;   // pinned host memory, [96]: queue positions per path depth of the last path-tracing pass that finished (0xFFFFFFFF: none yet)
 };
 
 struct WavefrontBuffers {
@@ -706,9 +707,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
 
 // film->splat(px, py, col) for every sample of the pass, Renderer.h:745. CAMERA: the sample is derived from the slot
 // number (path tracing, see camera_sample); otherwise ray generation has stored it.
+// What the host wants to know about a path-tracing pass before it enqueues a later one: how many queue positions every
+// depth had (it starts the tail kernel at the first depth that fits one round of it). Written to pinned host memory by
+// the last kernel of the pass; the host reads it whenever it gets there, no synchronisation (any depth is correct).
+__device__ __forceinline__ void publish_depth_stats(const WfPtrs& w)
+{
+    if (blockIdx.x != 0 || threadIdx.x >= 96u || !w.depth_stats) return;
+    uint32_t blocks = 0;
+    for (int c = 0; c < kQueueStreams; c++) blocks = max(blocks, (w.cnt[stream_word(threadIdx.x, (uint32_t)c)] + 63u) >> 6);
+    w.depth_stats[threadIdx.x] = blocks * (uint32_t)(kQueueStreams * 64);
+}
+
 template <bool CAMERA>
 __global__ __launch_bounds__(kBlock) void k_film_accumulate(WfPtrs w, PassParams pp, int filter)
 {
+    if constexpr (CAMERA) publish_depth_stats(w);
     const uint32_t slot = global_thread();
     float fx, fy;
     if constexpr (CAMERA) { Rng rng; if (!camera_sample(w, pp, slot, fx, fy, rng)) return; }
@@ -723,6 +736,7 @@ __global__ __launch_bounds__(kBlock) void k_film_accumulate(WfPtrs w, PassParams
 template <bool CAMERA>
 __global__ __launch_bounds__(kBlock) void k_film_accumulate_box(WfPtrs w, PassParams pp, int phase)
 {
+    if constexpr (CAMERA) { if (phase == 1) publish_depth_stats(w); }
     const uint32_t slot = global_thread();
     float fx, fy;
     if constexpr (CAMERA) { Rng rng; if (!camera_sample(w, pp, slot, fx, fy, rng)) return; }
@@ -1323,6 +1337,7 @@ inline int wavefront_alloc(rtx_ctx* c, int lane, const rtx_settings& st)
     p.film = c->b_film.as<float>(); p.tile_samples = c->b_tile_samples.as<uint32_t>();
     p.P = (uint32_t)n_local * 256u; p.W = (uint32_t)c->cam.width; p.H = (uint32_t)c->cam.height; p.tiles_x = c->tiles_x; p.n_tiles = n_tiles;
     p.tile_mul = mul; p.tile_add = add; p.n_local_tiles = n_local;
+    p.depth_stats = c->depth_stats;
     return RTX_OK;
 }
 
@@ -1450,7 +1465,14 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         };
         uint32_t* qin = w.qa; uint32_t* qout = w.qb;
         // from depth c->tail_from_depth on (few paths left) one launch walks the rest of every path, see k_pt_tail
-        const uint32_t tail_from = (cw || c->tail_from_depth == 0u) ? 0xFFFFFFFFu : c->tail_from_depth;
+        // (the first depth, not before c->tail_from_depth, whose queue fit one round of the tail kernel's waves in the last pass
+        // the device has reported; the report lags by the passes in flight, and any depth gives the same film)
+        uint32_t tail_from = 0xFFFFFFFFu;
+        if (!cw && c->tail_from_depth != 0u && c->depth_stats) {
+            const volatile uint32_t* ds = c->depth_stats;
+            const uint32_t fits = (uint32_t)c->resident_tail_blocks * (uint32_t)(kBlock / 64) * 64u;
+            for (uint32_t d = std::max(1u, c->tail_from_depth); d <= st.max_bounces && d < 96u; d++) if (ds[d] <= fits) { tail_from = d; break; }
+        }
         bool tail_done = false;
         for (uint32_t d = 0; d <= st.max_bounces; d++) {
             pp.depth = d;
