@@ -469,14 +469,15 @@ def cpu_baseline(pkg, scene, cam, args):
     return out
 
 
-# algorithmic bytes of path state a sample moves through HBM-side memory between the kernels of a pass: per sample
-# ray generation writes its slot (ray 24, film position 8, throughput + radiance 24, rng 8, mis / flags 8, queue 4) and the
-# film kernel reads radiance + position and updates the pixel (12 + 8 + 24); per closest-hit ray the traversal reads the
-# ray and writes the hit (24 + 20 + 4 queue) and the shade kernel reads the slot (ray, hit, throughput, radiance, rng, mis,
-# flags, queue: 112), the triangle's shading record (96) and a texel (12), and writes the continued ray (24 + 12 + 16 + 4
-# queue); per shadow ray the shade kernel writes and the traversal reads segment, value and path (40 each way) and adds to
-# the radiance (24)
-PT_BYTES_PER_SAMPLE, PT_BYTES_PER_CLOSEST, PT_BYTES_PER_SHADOW = 76 + 44, 48 + 220 + 56, 80 + 24
+# algorithmic bytes of path state a sample moves through HBM-side memory between the kernels of a pass. Per sample: the
+# closest-hit kernel of depth 0 generates the camera ray where it fetches it and writes the hit (20), the shade kernel of
+# depth 0 reads the hit (20) and starts the radiance sum (12), the film kernel reads it and updates the pixel (12 + 24).
+# Per closest-hit ray the shade kernel reads the triangle's shading record (96) and a texel (12) and writes what a continued
+# path needs (ray 24, throughput 12, generator / mis / flags 16, queue 4). Per closest-hit ray BEHIND depth 0 the traversal
+# also reads queue and ray and writes the hit (4 + 24 + 20) and the shade kernel reads the slot (queue, hit, ray,
+# throughput, radiance, generator, mis, flags: 88). Per shadow ray the shade kernel writes and the traversal reads segment,
+# value and path (40 each way) and adds to the radiance (24).
+PT_BYTES_PER_SAMPLE, PT_BYTES_PER_CLOSEST, PT_BYTES_PER_BOUNCE_RAY, PT_BYTES_PER_SHADOW = 20 + 20 + 12 + 36, 96 + 12 + 56, 48 + 88, 80 + 24
 
 
 def pathtrace_side(pkg, scenes, lib, core, torch, dist, world, rank, dev, args, all_reduce, prof):
@@ -563,9 +564,10 @@ def pathtrace_roofline(core, s_per_pass, prof):
     k = w["samples"]
     per = {key: w[key] / k for key in ("closest_rays", "shadow_rays", "nodes", "tris", "tri_groups")}
     flops = (4 * SLAB_FLOPS * w["nodes"] + TRI_FLOPS * w["tris"]) / 2
-    state_bytes = (PT_BYTES_PER_SAMPLE * w["samples"] + PT_BYTES_PER_CLOSEST * w["closest_rays"] + PT_BYTES_PER_SHADOW * w["shadow_rays"]) / 2
+    state_bytes = (PT_BYTES_PER_SAMPLE * w["samples"] + PT_BYTES_PER_CLOSEST * w["closest_rays"] + PT_BYTES_PER_BOUNCE_RAY * max(0, w["closest_rays"] - w["samples"])
+                   + PT_BYTES_PER_SHADOW * w["shadow_rays"]) / 2
     pmc = prof["pmc"].get("pathtrace", {})
-    r = {"bound": "valu (traversal kernels) + hbm (ray generation, shading, film)", "ms_per_pass": round(s_per_pass * 1e3, 4),
+    r = {"bound": "valu (traversal kernels) + hbm (shading, film)", "ms_per_pass": round(s_per_pass * 1e3, 4),
          "rays_per_sample": {"closest": round(per["closest_rays"], 3), "shadow": round(per["shadow_rays"], 3)},
          "nodes_per_sample": round(per["nodes"], 2), "tris_per_sample": round(per["tris"], 2),
          "traversal_flops_per_pass": int(flops), "state_bytes_per_pass": int(state_bytes),

@@ -500,6 +500,37 @@ def test_passes_in_flight_equal_one_pass_per_call(pkg, lib, lib_tuning, core, sc
     assert differ < 1e-3 and abs(a.mean() - b.mean()) < 1e-5 * b.mean()
 
 
+# ---- the late depths in one launch, regrouped shade items: schedules, not results -----------------
+
+def test_tail_kernel_and_regrouping_leave_the_film_bit_identical(pkg, lib, lib_tuning, scenes, monkeypatch):
+    """The path tracer's late depths run in one launch (a wave carries 64 paths to their ends) once a pass has reported
+    queue sizes, and its shade kernels sort their items by class inside a workgroup. Both are schedules: every path
+    computes and sums what it would as a plain wavefront. 640x360 mixed-material scene under the environment map with
+    MIS, 12 passes, one per call (the report of pass k is there for pass k + 1) and four per call; the shipped library
+    against the tuning build with both switched off. Only the box filter's strays (atomic adds) may differ."""
+    scene, cam_kw = scenes.mixed_scene(48), scenes.mixed_camera()
+    st = pkg.make_settings(total_spp=12, max_bounces=5, use_mis=1, seed=21)
+    films = {}
+    for name, which, env, per_call in (("shipped, one pass per call", lib, {}, 1), ("shipped, four passes per call", lib, {}, 4),
+                                       ("plain wavefront", lib_tuning, {"RTX_TAIL_FROM": "0", "RTX_REGROUP_FROM": "99"}, 1)):
+        for k in ("RTX_TAIL_FROM", "RTX_REGROUP_FROM"): monkeypatch.delenv(k, raising=False)
+        for k, v in env.items(): monkeypatch.setenv(k, v)
+        c = pkg.Core(0, which)              # the switches are read when a context is created
+        c.upload_scene(scene); c.set_camera(pkg.look_at(which, width=640, height=360, **cam_kw)); c.set_settings(st); c.clear()
+        for _ in range(12 // per_call):
+            c.render_passes(per_call)
+        f, spp, _ = c.film()
+        assert spp == 12
+        films[name] = f
+        c.close()
+    ref = films["plain wavefront"]
+    for name, f in films.items():
+        same = (f.view(np.uint32) == ref.view(np.uint32)).all(-1)
+        print(f"{name}: {1.0 - same.mean():.5%} of pixels not bit-identical to the plain wavefront")
+        assert (~same).mean() < 1e-3
+        np.testing.assert_allclose(f[~same], ref[~same], rtol=1e-5, atol=1e-6)
+
+
 # ---- a sample whose radiance is not a number is the reference's own result ---------------------
 
 def test_non_finite_sample_is_the_oracles(pkg, lib, core, orc, scenes):

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Builds profiles/r02_pmc.json (what bench.py reads for the counter-derived fields of its roofline blocks) from the
+"""Builds profiles/rNN_pmc.json (what bench.py reads for the counter-derived fields of its roofline blocks) from the
 raw summaries tools/pmc_json.py prints:
 
-    python tools/pmc_build.py --headline raw_headline.json --big raw_big.json --pathtrace raw_pt.json --passes 12 --out profiles/r02_pmc.json
+    python tools/pmc_build.py --headline raw_headline.json --big raw_big.json --pathtrace raw_pt.json --passes 12 --out profiles/r03_pmc.json --tag r03
 
 headline / big: the k_closest<false> row (1080p primaries of the 1 M-triangle soup; 4K primaries of the 10 M-triangle
 terrain). pathtrace: every kernel of `--passes` 1080p passes of the mixed-material scene, one pass in flight."""
@@ -29,8 +29,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--headline"); ap.add_argument("--big"); ap.add_argument("--pathtrace")
     ap.add_argument("--passes", type=int, default=12)
-    ap.add_argument("--out", default="profiles/r02_pmc.json")
-    ap.add_argument("--tag", default="r02")
+    ap.add_argument("--out", default="profiles/r03_pmc.json")
+    ap.add_argument("--tag", default="r03")
     a = ap.parse_args()
     out = {"note": "rocprofv3 --pmc passes (tools/pmc_collect.sh), mean per dispatch (tools/pmc_json.py); formulas in tools/pmc_json.py"}
     if a.headline:
@@ -41,7 +41,7 @@ def main():
         raw = json.load(open(a.pathtrace))
         kernels, total_bytes, total_us = {}, 0, 0.0
         for name, v in raw.items():
-            if name.startswith("__amd") or "devbuild" in name or v.get("dispatches", 0) < a.passes:
+            if name.startswith("__amd") or "devbuild" in name or v.get("dispatches", 0) < a.passes // 2:
                 continue
             per_pass = v["dispatches"] / a.passes
             kernels[name] = {"launches_per_pass": round(per_pass, 2), "avg_us": round(v.get("duration_ns", 0) / 1e3, 1),
@@ -51,7 +51,7 @@ def main():
             total_bytes += per_pass * (v.get("hbm_bytes_per_launch") or 0)
             total_us += per_pass * v.get("duration_ns", 0) / 1e3
         out["pathtrace"] = {"kernels": kernels, "hbm_bytes_per_pass": int(total_bytes), "kernel_us_per_pass": round(total_us, 1),
-                            "source": f"profiles/{a.tag}_pmc_pathtrace_raw.json: RTX_PIPELINE=1 tools/pt_profile.py --single 0 --passes 12 (4 warm-up + 12 passes of the mixed-material scene, 1920x1080, one pass in flight)"}
+                            "source": f"profiles/{a.tag}_pmc_pathtrace_raw.json: RTX_LIBRARY=tuning RTX_PIPELINE=1 tools/pt_profile.py --single 0 --passes 12 (4 warm-up + 12 passes of the mixed-material scene, 1920x1080, one pass in flight)"}
     json.dump(out, open(a.out, "w"), indent=1)
     print(json.dumps(out)[:600])
 
