@@ -74,6 +74,7 @@ struct WavefrontBuffers {
     DevBuf ray, hit, T, L, xy, key, dim, mis, flags, qa, qb, cnt, sseg, sval, sxy, spath, vpl, vpl_total, tile_off, ir_vis;
     WfPtrs p{};
     uint32_t vpl_capacity = 0;
+    bool cnt_clean = false;      // the last pass on these buffers zeroed the counters itself when it was done with them (path tracing, box filter)
 };
 
 struct PassParams {
@@ -733,10 +734,13 @@ __global__ __launch_bounds__(kBlock) void k_film_accumulate(WfPtrs w, PassParams
 // the pixel it was generated for, unless x + r rounded up to the next integer. Phase 0 adds the samples that stay in
 // their own pixel with plain loads and stores (one sample per pixel per pass, nobody else writes it in this
 // launch); phase 1, a second launch, adds the few strays with float atomics.
+// clean (second launch only): the pass is done with its counters (queue lengths, work counters) and zeroes them for the
+// next pass on the same buffers, which then needs no memset of its own
 template <bool CAMERA>
-__global__ __launch_bounds__(kBlock) void k_film_accumulate_box(WfPtrs w, PassParams pp, int phase)
+__global__ __launch_bounds__(kBlock) void k_film_accumulate_box(WfPtrs w, PassParams pp, int phase, int clean)
 {
-    if constexpr (CAMERA) { if (phase == 1) publish_depth_stats(w); }
+    if constexpr (CAMERA) { if (phase == 0) publish_depth_stats(w); }
+    if (phase == 1 && clean) for (uint32_t i = global_thread(); i < (uint32_t)kCounterWords; i += gridDim.x * (uint32_t)kBlock) w.cnt[i] = 0u;
     const uint32_t slot = global_thread();
     float fx, fy;
     if constexpr (CAMERA) { Rng rng; if (!camera_sample(w, pp, slot, fx, fy, rng)) return; }
@@ -755,12 +759,12 @@ __global__ __launch_bounds__(kBlock) void k_film_accumulate_box(WfPtrs w, PassPa
 }
 
 // camera: the samples are derived from the slot numbers (path tracing) instead of read from what ray generation stored
-inline void launch_film_accumulate(const WfPtrs& w, const PassParams& pp, bool camera, int filter, dim3 grid, dim3 blk, hipStream_t s)
+inline void launch_film_accumulate(const WfPtrs& w, const PassParams& pp, bool camera, int filter, dim3 grid, dim3 blk, hipStream_t s, bool clean_counters = false)
 {
     if (filter == (int)RTX_FT_BOX) {
         for (int phase = 0; phase < 2; phase++) {
-            if (camera) hipLaunchKernelGGL(k_film_accumulate_box<true>, grid, blk, 0, s, w, pp, phase);
-            else hipLaunchKernelGGL(k_film_accumulate_box<false>, grid, blk, 0, s, w, pp, phase);
+            if (camera) hipLaunchKernelGGL(k_film_accumulate_box<true>, grid, blk, 0, s, w, pp, phase, clean_counters ? 1 : 0);
+            else hipLaunchKernelGGL(k_film_accumulate_box<false>, grid, blk, 0, s, w, pp, phase, 0);
         }
     } else if (camera) hipLaunchKernelGGL(k_film_accumulate<true>, grid, blk, 0, s, w, pp, filter);
     else hipLaunchKernelGGL(k_film_accumulate<false>, grid, blk, 0, s, w, pp, filter);
@@ -1370,6 +1374,7 @@ inline int wavefront_aov(rtx_ctx* c, float* color, float* albedo, float* normal)
         int rc = wavefront_alloc(c, 0, whole); if (rc) return rc;
     }
     WfPtrs w = c->wf[0]->p; hipStream_t s = c->stream;
+    c->wf[0]->cnt_clean = false;
     const dim3 blk(kBlock), gridP((w.P + kBlock - 1) / kBlock), gridQ(std::min<uint32_t>((w.P + kBlock - 1) / kBlock, kMaxGridBlocks)),
                gridT(std::min<uint32_t>((w.P + kBlock - 1) / kBlock, (uint32_t)c->resident_blocks));
     const size_t plane = (size_t)w.W * w.H * 3 * sizeof(float);
@@ -1412,7 +1417,9 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
     c->spp++;                                            // Film::incrementSPP, RTBase/Imaging.h:403
     PassParams pp; pp.st = st; pp.spp = c->spp; pp.depth = 0;
     pp.sample_index = (st.shard_mode == 2 && st.shard_world > 1) ? (uint32_t)(c->spp - 1) * (uint32_t)st.shard_world + (uint32_t)st.shard_rank + 1u : (uint32_t)c->spp;
-    if (hipMemsetAsync(w.cnt, 0, kCounterWords * 4, s) != hipSuccess) return RTX_ERR_HIP;
+    const bool counters_zero = b.cnt_clean;
+    b.cnt_clean = false;
+    if (!counters_zero && hipMemsetAsync(w.cnt, 0, kCounterWords * 4, s) != hipSuccess) return RTX_ERR_HIP;
 
     const bool cw = c->count_work;                       // instrumented kernels (rtx_count_render_work)
     unsigned long long* ctr = cw ? c->b_counters.as<unsigned long long>() : nullptr;
@@ -1495,7 +1502,10 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         if (!tail_done) mixed(st.max_bounces + 1u, qin);
         if (film_wait && hipStreamWaitEvent(s, film_wait, 0) != hipSuccess) return RTX_ERR_HIP;
         pp.depth = 0;
-        launch_film_accumulate(w, pp, true, (int)st.filter, gridP, blk, s);
+        // (the instrumented passes leave their counters for the caller to read)
+        const bool clean_after = !cw && st.filter == RTX_FT_BOX;
+        launch_film_accumulate(w, pp, true, (int)st.filter, gridP, blk, s, clean_after);
+        b.cnt_clean = clean_after;
         c->stats.samples += (uint64_t)w.W * w.H;
     } else if (st.algorithm == RTX_AL_LIGHT_TRACE) {
         hipLaunchKernelGGL(k_lt_emit, gridP, blk, 0, s, w, dscene, c->dcam, pp);
