@@ -75,9 +75,6 @@ struct rtx_ctx {
     uint32_t spill_entries = 0;    // entries per lane in b_spill
     uint32_t stack_need = 0;       // traversal-stack entries a ray of the current scene can need at most
     void* na_scratch = nullptr;    // this device's copy of the static scratch of the no-allocation entry point
-    rtx::DevBuf b_steal;           // closest-hit launches with work stealing: work counters, then the board (directory bits, done count, done flag, offers)
-    rtx::DevBuf b_steal_key, b_steal_pending;   // per item: merged candidate (all ones between launches), tokens (zero between launches)
-    int steal = 1;                 // rtx_trace_closest_device: launches that fill the grid use k_closest_steal (RTX_STEAL=0: never)
     rtx::DevBuf b_rest;            // ray queries: items the packet kernel left to the per-lane kernel
     rtx::DevBuf b_io_a, b_io_b;    // staging for the host-pointer entry points
     rtx::PinBuf pin_in, pin_out;

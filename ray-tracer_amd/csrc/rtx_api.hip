@@ -230,7 +230,6 @@ static int create_resources(rtx_ctx* c, int device)
     if (const char* v = tuning_env("RTX_RAYS_PER_BLOCK")) c->rays_per_block = std::max(1, std::min(kBlock, atoi(v)));
     if (const char* v = tuning_env("RTX_PIPELINE")) c->pipeline = std::max(1, std::min(kPipeline, atoi(v)));
     c->tail_stats = tuning_env("RTX_DEBUG_COUNTERS") != nullptr;
-    if (const char* v = tuning_env("RTX_STEAL")) c->steal = atoi(v);
     if (const char* v = tuning_env("RTX_TAIL_FROM")) c->tail_from_depth = (uint32_t)std::max(0, atoi(v));
     if (const char* v = tuning_env("RTX_REGROUP_FROM")) c->regroup_from_depth = (uint32_t)std::max(0, atoi(v));
     HIP_TRY(hipHostMalloc((void**)&c->depth_stats, 96 * sizeof(uint32_t), hipHostMallocDefault));
@@ -563,26 +562,7 @@ int rtx_trace_closest_device(rtx_ctx* c, const rtx_ray* rays, size_t n, rtx_hit*
 #undef RTX_AB
     } else
 #endif
-    if (c->steal && n >= (size_t)c->resident_blocks * (kBlock / 64) * 64) {
-        // the launch fills the grid: waves that run out of rays take pending subtrees from the others (k_closest_steal)
-        constexpr size_t kBoardWords = kWorkSlotWords + kStealWaves / 32 + 32 + 32;
-        const size_t board_bytes = kBoardWords * 4 + (size_t)kStealWaves * 8;
-        HIP_TRY(c->b_steal.ensure(board_bytes));
-        if (c->b_steal_key.bytes < n * 8) {
-            // (the kernel leaves both arrays as it found them: all ones and zero)
-            HIP_TRY(c->b_steal_key.ensure(n * 8)); HIP_TRY(c->b_steal_pending.ensure(n * 4));
-            HIP_TRY(hipMemsetAsync(c->b_steal_key.p, 0xFF, c->b_steal_key.bytes, c->stream));
-            HIP_TRY(hipMemsetAsync(c->b_steal_pending.p, 0, c->b_steal_pending.bytes, c->stream));
-        }
-        HIP_TRY(hipMemsetAsync(c->b_steal.p, 0, board_bytes, c->stream));
-        uint32_t* w32 = c->b_steal.as<uint32_t>();
-        StealCtx sx;
-        sx.bits = w32 + kWorkSlotWords; sx.done_count = sx.bits + kStealWaves / 32; sx.all_done = sx.done_count + 32;
-        sx.offer = (unsigned long long*)(w32 + kBoardWords); sx.key = c->b_steal_key.as<unsigned long long>(); sx.pending = c->b_steal_pending.as<uint32_t>();
-        sx.mode = (uint32_t)c->steal;
-        hipLaunchKernelGGL(k_closest_steal, dim3(dyn_grid_for(c, n)), dim3(kBlock), 0, c->stream, c->dscene, rays, (uint32_t)n, hits, c->b_spill.as<uint2>(),
-                           (uint32_t)(kMaxGridBlocks * kBlock), w32, sx);
-    } else {
+    {
         uint32_t* wc = c->b_counters.as<uint32_t>() + kWorkSlotWords;
         const uint32_t* queue = nullptr; const uint32_t* n_dev = nullptr;
 #ifdef RTX_TUNING

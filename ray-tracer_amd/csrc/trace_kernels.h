@@ -93,18 +93,6 @@ __global__ __launch_bounds__(kBlock) void k_closest(DeviceScene sc, const rtx_ra
     traverse_dyn<ClosestPolicy, kModeClosest, COUNT, kRefillClosest, kBlock, kLdsStack, kTriUnroll, kLeafLanesClosest, COUNT ? 0 : kShare>(sc, stk, n_dev ? *n_dev : n_host, work_counter, pol, counters, &ts);
 }
 
-// The same with work stealing between workgroups (traverse_dyn's STEAL mode) for launches that fill the grid: waves
-// whose rays are done take pending subtrees of the rays that are still walked elsewhere. Same hit records.
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_closest_steal(DeviceScene sc, const rtx_ray* __restrict__ rays, uint32_t n, rtx_hit* __restrict__ hits,
-                                                          uint2* spill, uint32_t spill_stride, uint32_t* work_counter, StealCtx steal)
-{
-    __shared__ unsigned long long lds[kBlock * kLdsStack];
-    LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
-    ClosestPolicy pol{sc, rays, nullptr, hits};
-    __shared__ TailShare<kBlock> ts;
-    traverse_dyn<ClosestPolicy, kModeClosest, false, kRefillClosest, kBlock, kLdsStack, kTriUnroll, kLeafLanesClosest, kShare, false, true>(sc, stk, n, work_counter, pol, nullptr, &ts, &steal);
-}
-
 #ifdef RTX_TUNING
 // (Tuning build only: measured slower than the per-lane kernel on camera rays at 1080p, 0.70 vs 0.58 ms on the
 // 1 M-triangle soup and 1.23 vs 1.17 ms per path-traced pass of the mixed scene, faster only at 4K, 1.66 vs 1.89 ms;

@@ -81,55 +81,13 @@ __device__ __forceinline__ uint32_t nth_set_bit(unsigned long long m, uint32_t n
 
 constexpr int kModeClosest = 0, kModeAny = 1, kModeMixed = 2;
 
-// Work stealing between workgroups (STEAL, closest-hit launches large enough to fill the grid). Tail sharing keeps the
-// lanes of a WAVE busy once the counters are dry, but the launch still ends with the unluckiest wave: the mean wave is
-// done 14 % before the last one. With STEAL a wave whose rays are done does not leave: wave 0 of its workgroup stays and
-// takes pending subtrees other waves offer. Protocol, every cross-workgroup access a relaxed device-scope atomic (no
-// fences: a release at device scope would write back the L2):
-//   offer[w]    one 64-bit word per wave of the grid: 0 = empty, else (child reference << 32) | (item + 1). The owner of
-//               a long ray pops its newest pending subtree and stores it there (plain atomic store, fire and forget);
-//               bits[] is a directory of the waves with an offer out. A thief claims an offer with a compare-and-swap
-//               back to 0, fetches the ray by its item index and walks the subtree, its own idle lanes helping.
-//   pending[k]  tokens of ray k: one for the owner from its first prepayment on, one per offer from before it is
-//               published until the thief is done. Tokens are prepaid an iteration ahead (the counter of outstanding
-//               vector memory operations is in order, so a wait for a later load implies the add has completed) and
-//               refunded if unused. Whoever returns the last token writes the hit record.
-//   key[k]      best candidate of ray k over owner and thieves, packed so that an unsigned minimum is the reference's
-//               rule; all ones when idle (the finaliser puts that back, pending[k] returns to 0 by itself).
-// Candidates and arithmetic are unchanged and the minimum is order-independent: same hits bit for bit. Nothing waits
-// for another wave: a thief polls (bounded) until every wave has reported its own rays done, and a wave takes back its
-// own unclaimed offer before it reports.
-struct StealCtx {
-    uint32_t* bits;                // [kStealWaves / 32], zero at launch
-    uint32_t* done_count;          // waves whose own rays are done (a line of its own), zero at launch
-    uint32_t* all_done;            // set by the last of them (a line of its own; polled, never the target of an atomic)
-    unsigned long long* offer;     // [kStealWaves], zero at launch
-    unsigned long long* key;       // [items], all ones between launches
-    uint32_t* pending;             // [items], zero between launches
-    uint32_t mode;                 // 1: everything; (measurements) 2: no offers, the waves only report and poll; 3: offers but no thieves
-};
-constexpr int kStealWaves = 8192;              // waves of the largest grid (2048 workgroups of 4)
-constexpr uint32_t kStealAge = 6;              // tail iterations a ray must have lasted before its owner prepays tokens
-constexpr int kStealParts = 32;                // partitions of the directory: a thief watches the words whose index is its workgroup's number modulo this
-template <class T> __device__ __forceinline__ T dev_load(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <class T> __device__ __forceinline__ void dev_store(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// every vector memory operation this wave has issued so far has completed (in-order counter)
-__device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
 // LOCAL: the n items belong to the calling WAVE alone (n is wave-uniform and may differ between the waves of a workgroup;
 // `work` is not used): lanes take them in order as they fall idle, and once they are handed out the idle lanes help (SHARE).
 // The path tracer's tail kernel walks the few rays of a wave's own paths this way, depth after depth, without a launch.
-template <class Policy, int MODE, bool COUNT, int REFILL, int BLOCK, int LDS_N, int TRI_UNROLL, int SCHED, int SHARE = 0, bool LOCAL = false, bool STEAL = false>
+template <class Policy, int MODE, bool COUNT, int REFILL, int BLOCK, int LDS_N, int TRI_UNROLL, int SCHED, int SHARE = 0, bool LOCAL = false>
 __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BLOCK, LDS_N>& stk, uint32_t n, uint32_t* work,
-                                             Policy& pol, unsigned long long* counters, TailShare<BLOCK>* ts = nullptr, const StealCtx* steal = nullptr)
+                                             Policy& pol, unsigned long long* counters, TailShare<BLOCK>* ts = nullptr)
 {
-    static_assert(!STEAL || (MODE == kModeClosest && SHARE != 0 && !LOCAL && !COUNT), "stealing: closest-hit launches with tail sharing");
-    // STEAL, per lane: tokens added to pending[item] and offers published for the lane's own ray, tail iterations it has lasted,
-    // whether the lane walks a subtree taken from another wave; per wave: an offer is out, the wave has reported done
-    uint32_t st_prepaid = 0, st_donated = 0, st_age = 0; bool st_stolen = false;
-    bool st_offer_out = false, st_reported = false; uint32_t st_iter = 0;
-    const uint32_t st_wave = blockIdx.x * (uint32_t)(BLOCK / 64) + (threadIdx.x >> 6);
-    const bool st_on = STEAL && steal && steal->offer && gridDim.x * (uint32_t)(BLOCK / 64) <= (uint32_t)kStealWaves;
     const uint32_t lane = threadIdx.x & 63u;
     constexpr uint32_t kNone = 0xFFFFFFFFu;
     // item values from kHelper up (except kNone): the lane helps the ray of lane (item & 63) of its wave
@@ -218,27 +176,6 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
                     }
                 }
             }
-            if constexpr (STEAL) {
-                if (ready && (st_stolen || st_prepaid != 0u)) {
-                    // the ray has (or may have) parts elsewhere: return this lane's tokens; the last holder writes the hit
-                    const uint32_t mine = st_stolen ? 1u : st_prepaid - st_donated;
-                    bool last = !st_stolen && st_donated == 0u;            // nothing was ever offered: the ray is this lane's alone
-                    if (last) __hip_atomic_fetch_sub(steal->pending + item, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else {
-                        if (best.pos != kNone) __hip_atomic_fetch_min(steal->key + item, pack_hit(best), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        vm_drain();                                        // the minimum is in before the tokens go back
-                        last = __hip_atomic_fetch_sub(steal->pending + item, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine;
-                        if (last) {
-                            const unsigned long long kk = __hip_atomic_exchange(steal->key + item, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            best.pos = (uint32_t)kk; best.t = __uint_as_float((uint32_t)(kk >> 32)); best.u = best.v = 0;
-                            if (best.pos != kNone) { float t; tri_test(sc.tris[best.pos], ox, oy, oz, dx, dy, dz, t, best.u, best.v); }
-                        }
-                    }
-                    if (last) pol.retire(item, best, true);
-                    item = kNone; st_stolen = false; st_prepaid = st_donated = 0u;
-                    ready = false;
-                }
-            }
             if (ready) {
                 pol.retire(item, best, true);
                 if constexpr (COUNT) pol.note(item, cnt.nodes - mark.nodes, cnt.tris - mark.tris);
@@ -295,7 +232,6 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
                 ox = o[0]; oy = o[1]; oz = o[2]; dx = d[0]; dy = d[1]; dz = d[2];
                 ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;                                    // Ray::init, Geometry.h:25
                 best.t = FLT_MAX; best.u = best.v = 0; best.pos = kNone; stk.sp = 0;
-                if constexpr (STEAL) { st_prepaid = st_donated = st_age = 0u; st_stolen = false; }
                 if constexpr (SHARE != 0) { if (tail) { ts->key[threadIdx.x] = pack_hit(best); ts->pending[threadIdx.x] = 0u; } }   // a fresh mailbox for the new ray
                 bound = RTX_IS_ANY ? (maxT + (fabsf(maxT) * kCullRel + kCullAbs)) : FLT_MAX;
                 // root box first (Geometry.h:509 / :571)
@@ -351,123 +287,6 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
                         if constexpr (COUNT) mark = cnt;
                     }
                 }
-            }
-        }
-        if constexpr (STEAL) {
-            if (st_on && exhausted && !spread && tail && steal->mode != 2u) {
-                // --- the owner side: prepay, then offer the newest pending subtree of the ray with the deepest stack ---
-                st_iter++;
-                const bool walking = cur != kDone && item < kHelper;            // the lane owns a ray, or walks a subtree it has taken
-                const bool owner = walking && !st_stolen;
-                if ((st_iter & 1u) == 0u) {
-                    // every other iteration: has a thief taken the offer; what have the others found for a ray that is walked in several places
-                    const unsigned long long out = st_offer_out ? dev_load(steal->offer + st_wave) : 1ull;
-                    if (walking && (st_stolen || st_donated != 0u)) {
-                        const unsigned long long seen = lds_read(&ts->key[threadIdx.x]), own = pack_hit(best);
-                        const unsigned long long local = seen < own ? seen : own;
-                        if ((uint32_t)local != kNone) __hip_atomic_fetch_min(steal->key + item, local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned long long g = dev_load(steal->key + item);
-                        if (g != ~0ull) { const float gt = __uint_as_float((uint32_t)(g >> 32)), nb = gt + (fabsf(gt) * kCullRel + kCullAbs); if (nb < bound) bound = nb; }
-                    }
-                    if (out == 0ull) st_offer_out = false;
-                }
-                if (owner) st_age++;
-                if (owner && st_prepaid == 0u && st_age >= kStealAge) {
-                    __hip_atomic_fetch_add(steal->pending + item, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the owner's token and one offer's
-                    st_prepaid = 2u; st_age = 0u;                                                       // (usable from the next iteration on)
-                }
-                // rays without a candidate yet: their pending subtrees cannot be pruned away, and giving the nearest one to a wave
-                // whose finds arrive late would cost a ray with candidates its pruning
-                const bool can_offer = owner && st_prepaid - st_donated >= 2u && st_age >= 1u && stk.sp >= 2 && st_donated < 200u
-                                       && best.pos == kNone && (uint32_t)lds_read(&ts->key[threadIdx.x]) == kNone;
-                const unsigned long long om = __ballot(can_offer);
-                if (!st_offer_out && om != 0ull) {
-                    // deepest stack first: the ray with the most work pending
-                    int depth = can_offer ? stk.sp : 0;
-                    for (int o = 32; o > 0; o >>= 1) depth = max(depth, __shfl_xor(depth, o, 64));
-                    const unsigned long long pick = __ballot(can_offer && stk.sp == depth);
-                    const bool me = can_offer && lane == (uint32_t)__builtin_ctzll(pick);
-                    bool published = false;
-                    if (me) {
-                        const uint2 e = stk.pop();
-                        vm_drain();                                                                     // the prepaid token is in memory
-                        dev_store(steal->offer + st_wave, ((unsigned long long)e.x << 32) | (unsigned long long)(item + 1u));
-                        __hip_atomic_fetch_or(steal->bits + (st_wave >> 5), 1u << (st_wave & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        st_donated++;
-                        __hip_atomic_fetch_add(steal->pending + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // the next offer's token
-                        st_prepaid++; st_age = 0u;
-                        published = true;
-                    }
-                    if (__any(published)) st_offer_out = true;
-                }
-            }
-            if (st_on && exhausted && !spread && __all(cur == kDone && item == kNone)) {
-                // --- the wave's own rays are done ---
-                uint32_t got_item = kNone, got_ref = 0;
-                if (st_offer_out) {
-                    // take back what nobody has claimed and walk it here
-                    unsigned long long v = 0;
-                    if (lane == 0) v = __hip_atomic_exchange(steal->offer + st_wave, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    v = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-                    st_offer_out = false;
-                    if (v != 0ull) { got_item = (uint32_t)v - 1u; got_ref = (uint32_t)(v >> 32); }
-                }
-                if (got_item == kNone && !st_reported) {
-                    st_reported = true;
-                    uint32_t before = 0;
-                    if (lane == 0) before = __hip_atomic_fetch_add(steal->done_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
-                    if (before + 1u == gridDim.x * (uint32_t)(BLOCK / 64) && lane == 0) dev_store(steal->all_done, 1u);
-                }
-                if (got_item == kNone && (threadIdx.x >> 6) == 0u && steal->mode != 3u) {
-                    // --- the thief side (wave 0 of the workgroup): poll the directory until an offer turns up or everybody is done ---
-                    // A workgroup watches one partition of the directory (the words whose index is its number modulo kStealParts):
-                    // an offer is then seen by a few dozen thieves, not by all of them (every probe of an offer word is traffic on
-                    // a line its owner, the slowest wave of the launch, polls too).
-                    const uint32_t words = (gridDim.x * (uint32_t)(BLOCK / 64) + 31u) >> 5;
-                    for (uint32_t polls = 0; polls < 200000u && got_item == kNone; polls++) {
-                        const uint32_t finished = dev_load(steal->all_done);
-                        const uint32_t wi = (blockIdx.x % (uint32_t)kStealParts) + lane * (uint32_t)kStealParts;
-                        const uint32_t b = wi < words ? dev_load(steal->bits + wi) : 0u;
-                        const unsigned long long hm = __ballot(b != 0u);
-                        if (hm != 0ull) {
-                            // a random word among those with offers, a random bit in it: the thieves must not all go for the same one
-                            hop = hop * 1664525u + 1013904223u;
-                            const uint32_t src = nth_set_bit(hm, (hop >> 16) % (uint32_t)__popcll(hm));
-                            const uint32_t bw = (uint32_t)__shfl((int)b, (int)src, 64);
-                            const uint32_t bit = nth_set_bit((unsigned long long)bw, (hop >> 8) % (uint32_t)__popc(bw));
-                            const uint32_t victim = (((blockIdx.x % (uint32_t)kStealParts) + src * (uint32_t)kStealParts) << 5) | bit;
-                            unsigned long long v = 0;
-                            if (lane == 0) {
-                                v = dev_load(steal->offer + victim);
-                                const bool stale = v == 0ull;
-                                if (!stale && !__hip_atomic_compare_exchange_strong(steal->offer + victim, &v, 0ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) v = 0ull;
-                                // claimed, or found empty: the directory bit is stale (the owner sets it again with its next offer); a lost race leaves it to the winner
-                                if (stale || v != 0ull) __hip_atomic_fetch_and(steal->bits + (victim >> 5), ~(1u << (victim & 31u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-                            v = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-                            if (v != 0ull) { got_item = (uint32_t)v - 1u; got_ref = (uint32_t)(v >> 32); }
-                        }
-                        if (got_item != kNone || finished) break;
-                        __builtin_amdgcn_s_sleep(127);
-                    }
-                }
-                if (got_item == kNone) break;
-                // lane 0 walks the subtree for ray got_item, the other lanes help through the tail-sharing mailboxes
-                if (lane == 0) {
-                    float o[3], d[3];
-                    pol.fetch(got_item, o, d, maxT);
-                    ox = o[0]; oy = o[1]; oz = o[2]; dx = d[0]; dy = d[1]; dz = d[2];
-                    ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
-                    best.t = FLT_MAX; best.u = best.v = 0; best.pos = kNone; stk.sp = 0;
-                    ts->key[threadIdx.x] = pack_hit(best); ts->pending[threadIdx.x] = 0u;
-                    const unsigned long long known = dev_load(steal->key + got_item);
-                    const float bt = __uint_as_float((uint32_t)(known >> 32));
-                    bound = known == ~0ull ? FLT_MAX : bt + (fabsf(bt) * kCullRel + kCullAbs);
-                    if (known != ~0ull) { best.t = bt; best.pos = (uint32_t)known; }      // (a candidate as good as any: keeps the lane's own pruning tight)
-                    item = got_item; cur = got_ref; st_stolen = true; st_prepaid = st_donated = st_age = 0u;
-                }
-                continue;
             }
         }
         if (exhausted && __all(cur == kDone && item == kNone)) break;
