@@ -62,6 +62,23 @@ def test_path_trace_per_sample_parity_cornell(pkg, lib, core, orc, scenes, mater
     assert (g > 0).any()
 
 
+def test_path_trace_twelve_bounces_partial_tiles(pkg, lib, core, orc, scenes):
+    """Long paths in a closed box (most survive every bounce, so the streamed queues stay near their capacity depth after
+    depth and the late depths hold many rounds of the tail kernel's shade / traversal steps) on a film whose last tile
+    row and column are partial (250x130: slots without a sample at every depth-0 kernel). Sample by sample against the
+    oracle; passes 2 and 3 run their late depths in the tail kernel (pass 1 has no report of queue sizes yet)."""
+    st, osc = _setup(pkg, lib, core, orc, scenes.cornell_box("mixed"), scenes.cornell_camera(), 250, 130, total_spp=3, seed=5, max_bounces=12, use_mis=1)
+    r = osc.renderer(st, threads=8, counter_rng=True)
+    prev_g = prev_o = 0
+    for k in range(3):
+        core.render_passes(1); r.render_passes(1)
+        g, spp, _ = core.film(); o, ospp, _ = r.film()
+        assert spp == ospp == k + 1
+        _assert_films_match(g - prev_g, o - prev_o, f"12 bounces, sample {k + 1}")
+        prev_g, prev_o = g, o
+    assert (g > 0).any()
+
+
 def test_path_trace_per_sample_parity_env_mis(pkg, lib, core, orc, scenes):
     """Every BSDF + environment-map importance sampling + MIS (use_mis on and off)."""
     scene = scenes.mixed_scene(32, (128, 64))
