@@ -90,7 +90,6 @@ struct DeviceScene {
     float env_inv_w, env_inv_h;
     float scene_centre[3], scene_radius;   // SceneBounds, SceneLoader.h:387-388
     uint32_t fine_per_wave;      // the last fine_per_wave items per wave of the grid are handed out item by item instead of in chunks (traverse_dyn.h); 0: none
-    uint32_t retire_at_refill;   // finished rays are retired in the trip that refills the wave (1) instead of the trip they finish in (0; measurements)
     uint32_t spread_below;       // launches with fewer items per wave of the grid than this are spread thin (traverse_dyn.h); 0: never
 };
 

@@ -325,8 +325,6 @@ int rtx_upload_scene(rtx_ctx* c, const rtx_scene_desc* d)
     ds.scene_radius = h.scene_radius;
     ds.spread_below = 32;
     ds.fine_per_wave = 192;
-    ds.retire_at_refill = 1;
-    if (const char* v = tuning_env("RTX_RETIRE_AT_REFILL")) ds.retire_at_refill = (uint32_t)atoi(v);
     if (const char* v = tuning_env("RTX_FINE")) ds.fine_per_wave = (uint32_t)std::max(0, std::min(4096, atoi(v)));   // tuning override
     if (const char* v = tuning_env("RTX_SPREAD")) ds.spread_below = (uint32_t)std::max(0, std::min(32, atoi(v)));   // tuning override
 

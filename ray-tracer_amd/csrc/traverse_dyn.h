@@ -163,13 +163,8 @@ __device__ __forceinline__ void traverse_dyn(const DeviceScene& sc, LaneStack<BL
                 }
             }
         }
-        // retire finished rays. While the queue still has items a finished ray's lane only waits for the next refill, so its
-        // hit is written then, together with the others' (REFILL lanes at once instead of the one or two that finish in a
-        // given trip: the retire code, its index load and its store run with a third of the lanes live instead of a few percent)
-        const bool finished = cur == kDone && item != kNone && (!SHARE || item < kHelper);
-        bool retire_now = true;
-        if (!exhausted && !tail && sc.retire_at_refill) retire_now = (uint32_t)__popcll(__ballot(cur == kDone && (item == kNone || finished))) >= refill;
-        if (finished && retire_now) {
+        // retire finished rays
+        if (cur == kDone && item != kNone && (!SHARE || item < kHelper)) {
             bool ready = true;
             if constexpr (SHARE) {
                 if (tail) {
