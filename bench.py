@@ -516,6 +516,12 @@ def pathtrace_side(pkg, scenes, lib, core, torch, dist, world, rank, dev, args, 
                                     "spp_timed": total, "scaling": scaling,
                                     "parallelism": f"spp split x{world} + one film all-reduce ({core.film_device()[1] * 4} bytes per rank) at the end, inside the timed region" if world > 1 else "1 GPU"}}
         if rank == 0 and world == 1:
+            # what a host that asks for one pass per call gets (RayTracer::renderMT's contract): no passes in flight beside each other
+            core.set_settings(base); core.clear(); core.render_passes(3)
+            t1 = time.perf_counter()
+            for _ in range(16):
+                core.render_passes(1)
+            out["pathtrace_ms_one_pass_per_call"] = round((time.perf_counter() - t1) / 16 * 1e3, 4)
             out["pathtrace_roofline"] = pathtrace_roofline(core, dt / total, prof)
             if not args.no_radiosity:
                 out["instant_radiosity"] = radiosity_side(pkg, core, args)

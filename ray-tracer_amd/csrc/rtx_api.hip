@@ -812,6 +812,8 @@ int rtx_count_render_work(rtx_ctx* c, int n_passes, uint64_t out[8])
     unsigned long long h[8];
     HIP_TRY(hipMemcpy(h, c->b_counters.p, sizeof h, hipMemcpyDeviceToHost));
     out[2] = h[0]; out[3] = h[1]; out[5] = h[5]; out[6] = h[6]; out[1] += h[6];
+    if (tuning_env("RTX_DEBUG_COUNTERS"))
+        fprintf(stderr, "[rtx] traversal trips of the instrumented passes, summed over waves: %llu node steps, %llu triangle steps, %llu outer trips\n", h[2], h[3], h[4]);
 #ifdef RTX_TUNING
     {
         // (the instrumented passes above ran the per-lane gather; one more plain pass for the packet walk's statistics)
