@@ -209,8 +209,11 @@ static int create_resources(rtx_ctx* c, int device)
         { int pc = 0; HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_closest_packet, kBlock, 0)); per_cu = std::min(per_cu, pc); }
 #endif
         c->resident_packet_blocks = std::max(1, std::min(kMaxGridBlocks, per_cu * prop.multiProcessorCount));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pt_tail, kBlock, 0));
-        c->resident_tail_blocks = std::max(1, std::min(kMaxGridBlocks, per_cu * prop.multiProcessorCount));
+        if (const char* v = tuning_env("RTX_TAIL_ROUNDS")) c->tail_rounds = std::max(0, std::min(2, atoi(v)));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pt_tail<1>, kBlock, 0));
+        c->resident_tail_blocks[0] = std::max(1, std::min(kMaxGridBlocks, per_cu * prop.multiProcessorCount));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pt_tail<2>, kBlock, 0));
+        c->resident_tail_blocks[1] = std::max(1, std::min(kMaxGridBlocks, per_cu * prop.multiProcessorCount));
         if (const char* v = tuning_env("RTX_IR_PACKET")) c->ir_packet = atoi(v);
         if (const char* v = tuning_env("RTX_PRIMARY_PACKET")) c->primary_packet = atoi(v);
         if (const char* v = tuning_env("RTX_QUERY_PACKET")) c->query_packet = atoi(v);

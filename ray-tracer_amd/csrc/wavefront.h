@@ -587,13 +587,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
 // the lists (live slots, their hits, pending shadow segments) sit in LDS, the path state stays in the slot arrays.
 // Every sum is taken in the order the wavefront kernels take it (a path's shadow ray of depth d before its emission at
 // depth d + 1), so the film is the same bit for bit whichever way the late depths run.
+template <int N>
 struct TailWaveLists {
-    uint32_t live[64];                                                 // path slots that go on, in list order
-    uint32_t hit_id[64]; float hit_t[64], hit_alpha[64], hit_beta[64], hit_gamma[64];   // closest hit of live[k]
-    float seg[6][64], val[3][64]; uint32_t seg_slot[64];               // shadow rays asked for by the last shade step
+    uint32_t live[N];                                                  // path slots that go on, in list order
+    uint32_t hit_id[N]; float hit_t[N], hit_alpha[N], hit_beta[N], hit_gamma[N];   // closest hit of live[k]
+    float seg[6][N], val[3][N]; uint32_t seg_slot[N];                  // shadow rays asked for by the last shade step
 };
+template <int N>
 struct PtTailPolicy {
-    const DeviceScene& sc; const WfPtrs& w; TailWaveLists& t; uint32_t n_live;
+    const DeviceScene& sc; const WfPtrs& w; TailWaveLists<N>& t; uint32_t n_live;
     __device__ __forceinline__ bool fetch(uint32_t k, float o[3], float d[3], float& maxT, bool& any) const
     {
         if (k < n_live) {
@@ -620,18 +622,22 @@ struct PtTailPolicy {
     __device__ __forceinline__ void note(uint32_t, uint32_t, uint32_t) const {}
 };
 constexpr int kTailRefill = 8;       // idle lanes at which a wave takes more of its own items
+// ROUNDS: a wave's task is ROUNDS blocks of 64 queue positions; it shades them 64 at a time and walks all their rays in
+// one wave-local traversal (fuller lanes per trip, fewer waves resident: the lists take 4 KB of LDS per block).
+template <int ROUNDS>
 __global__ __launch_bounds__(kBlock) void k_pt_tail(WfPtrs w, DeviceScene sc, CameraDev cam, PassParams pp, const uint32_t* __restrict__ qin, uint32_t task_index,
                                                     uint2* spill, uint32_t spill_stride RTX_PACKET_STATS(, unsigned long long* stats))
 {
+    constexpr uint32_t kTask = 64u * ROUNDS;
     RTX_PACKET_STATS(unsigned long long t_shade = 0, t_trace = 0, t_begin = stats ? wall_clock64() : 0ull; uint32_t n_rounds = 0, n_tasks_done = 0;)
     __shared__ unsigned long long lds[kBlock * kLdsStack];
     __shared__ TailShare<kBlock> ts;
     __shared__ StreamLens s_in;
-    __shared__ TailWaveLists s_lists[kBlock / 64];
+    __shared__ TailWaveLists<64 * ROUNDS> s_lists[kBlock / 64];
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     const uint32_t first_depth = pp.depth;
-    const uint32_t n_tasks = stream_load(w.cnt, first_depth, s_in) >> 6;       // (the only barrier: from here on the waves go their own ways)
-    TailWaveLists& t = s_lists[threadIdx.x >> 6];
+    const uint32_t n_tasks = stream_load(w.cnt, first_depth, s_in) / kTask;    // (the only barrier: from here on the waves go their own ways)
+    TailWaveLists<64 * ROUNDS>& t = s_lists[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
     for (;;) {
@@ -639,34 +645,46 @@ __global__ __launch_bounds__(kBlock) void k_pt_tail(WfPtrs w, DeviceScene sc, Ca
         if (lane == 0) task = atomicAdd(w.cnt + task_index, 1u);
         task = (uint32_t)__builtin_amdgcn_readfirstlane((int)task);
         if (task >= n_tasks) break;
-        const uint32_t i = task * 64u + lane;
-        bool have = stream_valid(s_in, i);
-        uint32_t slot = 0; rtx_hit h; h.id = 0; h.t = FLT_MAX; h.alpha = h.beta = h.gamma = 0.0f;
-        if (have) { slot = qin[i]; h = w.hit[slot]; }
+        uint32_t n_in = kTask;                                          // items to shade at this depth: queue positions first, the live list afterwards
         for (pp.depth = first_depth; ; pp.depth++) {
-            ShadeOut so; so.cont = so.shadow = false; so.sx = so.p2 = mk(0, 0, 0); so.sval = mkc(0, 0, 0);
+            uint32_t n_live = 0, n_seg = 0;
             RTX_PACKET_STATS(const unsigned long long c0 = stats ? wall_clock64() : 0ull;)
-            if (have) pt_shade_item<false>(w, sc, cam, pp, slot, h, so);
-            const unsigned long long mc = __ballot(so.cont), ms = __ballot(so.shadow);
-            RTX_PACKET_STATS(if (stats) { t_shade += wall_clock64() - c0; n_rounds++; })
-            const uint32_t n_live = (uint32_t)__popcll(mc), n_seg = (uint32_t)__popcll(ms);
-            if (n_live + n_seg == 0u) break;
-            if (so.cont) t.live[__popcll(mc & below)] = slot;
-            if (so.shadow) {
-                const uint32_t j = (uint32_t)__popcll(ms & below);
-                t.seg[0][j] = so.sx.x; t.seg[1][j] = so.sx.y; t.seg[2][j] = so.sx.z; t.seg[3][j] = so.p2.x; t.seg[4][j] = so.p2.y; t.seg[5][j] = so.p2.z;
-                t.val[0][j] = so.sval.r; t.val[1][j] = so.sval.g; t.val[2][j] = so.sval.b; t.seg_slot[j] = slot;
+            for (uint32_t base = 0; base < n_in; base += 64u) {
+                bool have; uint32_t slot = 0; rtx_hit h; h.id = 0; h.t = FLT_MAX; h.alpha = h.beta = h.gamma = 0.0f;
+                if (pp.depth == first_depth) {
+                    const uint32_t i = task * kTask + base + lane;
+                    have = stream_valid(s_in, i);
+                    if (have) { slot = qin[i]; h = w.hit[slot]; }
+                } else {
+                    const uint32_t k = base + lane;
+                    have = k < n_in;
+                    if (have) { slot = t.live[k]; h.id = t.hit_id[k]; h.t = t.hit_t[k]; h.alpha = t.hit_alpha[k]; h.beta = t.hit_beta[k]; h.gamma = t.hit_gamma[k]; }
+                }
+                ShadeOut so; so.cont = so.shadow = false; so.sx = so.p2 = mk(0, 0, 0); so.sval = mkc(0, 0, 0);
+                if (have) pt_shade_item<false>(w, sc, cam, pp, slot, h, so);
+                // survivors are packed to the front of the live list: they never reach the entries a later round still has to read
+                // (at most `base` of them so far), and this round has read its own
+                const unsigned long long mc = __ballot(so.cont), ms = __ballot(so.shadow);
+                if (so.cont) t.live[n_live + (uint32_t)__popcll(mc & below)] = slot;
+                if (so.shadow) {
+                    const uint32_t j = n_seg + (uint32_t)__popcll(ms & below);
+                    t.seg[0][j] = so.sx.x; t.seg[1][j] = so.sx.y; t.seg[2][j] = so.sx.z; t.seg[3][j] = so.p2.x; t.seg[4][j] = so.p2.y; t.seg[5][j] = so.p2.z;
+                    t.val[0][j] = so.sval.r; t.val[1][j] = so.sval.g; t.val[2][j] = so.sval.b; t.seg_slot[j] = slot;
+                }
+                n_live += (uint32_t)__popcll(mc); n_seg += (uint32_t)__popcll(ms);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             }
+            RTX_PACKET_STATS(if (stats) { t_shade += wall_clock64() - c0; n_rounds++; })
+            if (n_live + n_seg == 0u) break;
             // the lists and the slots' new state were written by other lanes than the ones that read them next
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            PtTailPolicy pol{sc, w, t, n_live};
+            PtTailPolicy<64 * ROUNDS> pol{sc, w, t, n_live};
             RTX_PACKET_STATS(const unsigned long long c1 = stats ? wall_clock64() : 0ull;)
-            traverse_dyn<PtTailPolicy, kModeMixed, false, kTailRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare, true>(sc, stk, n_live + n_seg, nullptr, pol, nullptr, &ts);
+            traverse_dyn<PtTailPolicy<64 * ROUNDS>, kModeMixed, false, kTailRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare, true>(sc, stk, n_live + n_seg, nullptr, pol, nullptr, &ts);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             RTX_PACKET_STATS(if (stats) t_trace += wall_clock64() - c1;)
             if (n_live == 0u) break;                                   // the shadow rays of the paths' last vertices
-            have = lane < n_live;
-            if (have) { slot = t.live[lane]; h.id = t.hit_id[lane]; h.t = t.hit_t[lane]; h.alpha = t.hit_alpha[lane]; h.beta = t.hit_beta[lane]; h.gamma = t.hit_gamma[lane]; }
+            n_in = n_live;
         }
         RTX_PACKET_STATS(n_tasks_done++;)
     }
@@ -1474,10 +1492,14 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         // from depth c->tail_from_depth on (few paths left) one launch walks the rest of every path, see k_pt_tail
         // (the first depth, not before c->tail_from_depth, whose queue fit one round of the tail kernel's waves in the last pass
         // the device has reported; the report lags by the passes in flight, and any depth gives the same film)
+        // (a wave takes two blocks of 64 positions at a time when passes overlap, one when this pass has the device to itself:
+        //  fuller lanes per instruction help the former, more waves the latter)
+        const int tail_rounds = c->tail_rounds ? c->tail_rounds : (c->passes_in_flight > 1 ? 2 : 1);
+        const int tail_blocks = c->resident_tail_blocks[tail_rounds - 1];
         uint32_t tail_from = 0xFFFFFFFFu;
         if (!cw && c->tail_from_depth != 0u && c->depth_stats) {
             const volatile uint32_t* ds = c->depth_stats;
-            const uint32_t fits = (uint32_t)c->resident_tail_blocks * (uint32_t)(kBlock / 64) * 64u;
+            const uint32_t fits = (uint32_t)tail_blocks * (uint32_t)(kBlock / 64) * 64u * (uint32_t)tail_rounds;
             for (uint32_t d = std::max(1u, c->tail_from_depth); d <= st.max_bounces && d < 96u; d++) if (ds[d] <= fits) { tail_from = d; break; }
         }
         bool tail_done = false;
@@ -1485,7 +1507,9 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
             pp.depth = d;
             if (d >= tail_from) {
                 mixed(d, qin);
-                hipLaunchKernelGGL(k_pt_tail, dim3(c->resident_tail_blocks), blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, (uint32_t)kShadowWorkBase, spill, sstride RTX_PACKET_STATS(, c->tail_stats ? c->b_counters.as<unsigned long long>() : nullptr));
+                RTX_PACKET_STATS(unsigned long long* stats = c->tail_stats ? c->b_counters.as<unsigned long long>() : nullptr;)
+                if (tail_rounds == 2) hipLaunchKernelGGL(k_pt_tail<2>, dim3(tail_blocks), blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, (uint32_t)kShadowWorkBase, spill, sstride RTX_PACKET_STATS(, stats));
+                else hipLaunchKernelGGL(k_pt_tail<1>, dim3(tail_blocks), blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, (uint32_t)kShadowWorkBase, spill, sstride RTX_PACKET_STATS(, stats));
                 tail_done = true;
                 break;
             }

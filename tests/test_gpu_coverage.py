@@ -503,7 +503,7 @@ def test_passes_in_flight_equal_one_pass_per_call(pkg, lib, lib_tuning, core, sc
 # ---- the late depths in one launch, regrouped shade items: schedules, not results -----------------
 
 def test_tail_kernel_and_regrouping_leave_the_film_bit_identical(pkg, lib, lib_tuning, scenes, monkeypatch):
-    """The path tracer's late depths run in one launch (a wave carries 64 paths to their ends) once a pass has reported
+    """The path tracer's late depths run in one launch (a wave carries 64 paths to their ends, 128 when passes overlap) once a pass has reported
     queue sizes, and its shade kernels sort their items by class inside a workgroup. Both are schedules: every path
     computes and sums what it would as a plain wavefront. 640x360 mixed-material scene under the environment map with
     MIS, 12 passes, one per call (the report of pass k is there for pass k + 1) and four per call; the shipped library
