@@ -371,38 +371,9 @@ __device__ __forceinline__ bool regroup_by_class(ShadeRegroup& s, bool active, u
     return mine;
 }
 
-// The path slots a workgroup's threads hold, sorted by a key below 8 (same counting sort as regroup_by_class, slots only).
-__device__ __forceinline__ bool sort_slots_by_key(ShadeRegroup& s, bool active, uint32_t key, uint32_t& slot)
-{
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    uint32_t rank = 0;
-#pragma unroll
-    for (uint32_t c = 0; c < 8u; c++) {
-        const unsigned long long m = __ballot(active && key == c);
-        if (lane == c) s.count[wave][c] = (uint32_t)__popcll(m);
-        if (key == c) rank = (uint32_t)__popcll(m & below);
-    }
-    __syncthreads();
-    if (threadIdx.x < (kBlock / 64) * 8) {
-        const uint32_t wv = threadIdx.x >> 3, c = threadIdx.x & 7u;
-        uint32_t b = 0;
-        for (uint32_t cc = 0; cc < c; cc++) for (uint32_t ww = 0; ww < kBlock / 64; ww++) b += s.count[ww][cc];
-        for (uint32_t ww = 0; ww < wv; ww++) b += s.count[ww][c];
-        s.base[wv][c] = b;
-        if (threadIdx.x == (kBlock / 64) * 8 - 1) s.total = b + s.count[wv][c];
-    }
-    __syncthreads();
-    if (active) s.slot[s.base[wave][key] + rank] = slot;
-    __syncthreads();
-    const bool mine = threadIdx.x < s.total;
-    if (mine) slot = s.slot[threadIdx.x];
-    return mine;
-}
-
 // What shading one path leaves for the queues: whether it goes on (its new ray and state are in the slot) and whether
 // it asks for a shadow ray (segment sx -> p2, value sval the path gains if the segment is free).
-struct ShadeOut { bool cont, shadow; V3 sx, p2; C3 sval; uint32_t oct; };
+struct ShadeOut { bool cont, shadow; V3 sx, p2; C3 sval; };
 // One depth of RayTracer::pathTrace, RTBase/Renderer.h:476-526, for the path in `slot` whose ray found hit `h`.
 // FIRST: depth 0, the path's state is the camera sample of the slot (nothing stored yet).
 template <bool FIRST>
@@ -447,7 +418,6 @@ __device__ __forceinline__ void pt_shade_item(const WfPtrs& w, const DeviceScene
                     V3 no = sd.x + (wi * kEps);
                     rtx_ray nr; nr.o[0] = no.x; nr.o[1] = no.y; nr.o[2] = no.z; nr.d[0] = wi.x; nr.d[1] = wi.y; nr.d[2] = wi.z;
                     w.ray[slot] = nr; st3(w.T + 3 * slot, T); w.mis[slot] = pdf;
-                    out.oct = (wi.x < 0.0f ? 1u : 0u) | (wi.y < 0.0f ? 2u : 0u) | (wi.z < 0.0f ? 4u : 0u);
                     w.flags[slot] = (flags & ~kFlagCanHitLight) | (isPureSpecular(*sd.mat) ? kFlagCanHitLight : 0u);
                     if constexpr (FIRST) w.key[slot] = rkey;
                     cont = true;
@@ -479,7 +449,7 @@ __device__ __forceinline__ void pt_shade_item(const WfPtrs& w, const DeviceScene
 // than the input had, P + kQueueSlack bounds them all), and the wave that holds the sorted workgroup's surface hits
 // moves round the streams of its group instead of filling one.
 template <bool FIRST, bool REGROUP>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pt_shade(WfPtrs w, DeviceScene sc, CameraDev cam, PassParams pp, const uint32_t* __restrict__ qin, uint32_t* qout, uint32_t sort_out)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pt_shade(WfPtrs w, DeviceScene sc, CameraDev cam, PassParams pp, const uint32_t* __restrict__ qin, uint32_t* qout)
 {
     __shared__ ShadeRegroup s_regroup;
     __shared__ StreamLens s_in;
@@ -505,16 +475,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             if (have && h.t < FLT_MAX) cls = sc.shade[h.id].shade_class;
             have = regroup_by_class(s_regroup, have, cls, slot, h);
         }
-        ShadeOut so; so.cont = so.shadow = false; so.sx = so.p2 = mk(0, 0, 0); so.sval = mkc(0, 0, 0); so.oct = 0;
+        ShadeOut so; so.cont = so.shadow = false; so.sx = so.p2 = mk(0, 0, 0); so.sval = mkc(0, 0, 0);
         if (have) pt_shade_item<FIRST>(w, sc, cam, pp, slot, h, so);
         cont = so.cont; shadow = so.shadow; p2 = so.p2; sval = so.sval; sx = so.sx;
-        const uint32_t shadow_slot = slot;
-        if (sort_out) cont = sort_slots_by_key(s_regroup, cont, so.oct, slot);
         const uint32_t stream = ((blockIdx.x & 3u) << 2) | (((threadIdx.x >> 6) + (blockIdx.x >> 2)) & 3u);
         const uint32_t qs = stream_push(shadow, w.cnt + stream_word(kShadowCounterBase + pp.depth, stream), stream);
         if (shadow) {
             float* s = w.sseg + 6 * (size_t)qs; s[0] = sx.x; s[1] = sx.y; s[2] = sx.z; s[3] = p2.x; s[4] = p2.y; s[5] = p2.z;
-            st3(w.sval + 3 * (size_t)qs, sval); w.spath[qs] = shadow_slot;
+            st3(w.sval + 3 * (size_t)qs, sval); w.spath[qs] = slot;
         }
         const uint32_t qc = stream_push(cont, w.cnt + stream_word(pp.depth + 1, stream), stream);
         if (cont) qout[qc] = slot;
@@ -1549,10 +1517,10 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
             else if (cw) hipLaunchKernelGGL(k_pt_closest_primary<true>, gridT, blk, 0, s, w, dscene, c->dcam, pp, (uint32_t)kClosestWorkBase, spill, sstride, ctr);
             else hipLaunchKernelGGL(k_pt_closest_primary<false>, gridT, blk, 0, s, w, dscene, c->dcam, pp, (uint32_t)kClosestWorkBase, spill, sstride, (unsigned long long*)nullptr);
             const bool regroup = d >= c->regroup_from_depth;
-            if (d == 0) { if (regroup) hipLaunchKernelGGL((k_pt_shade<true, true>), gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout, (uint32_t)(c->sort_out > (d > 0 ? 1 : 0)));
-                          else hipLaunchKernelGGL((k_pt_shade<true, false>), gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout, (uint32_t)(c->sort_out > (d > 0 ? 1 : 0))); }
-            else if (regroup) hipLaunchKernelGGL((k_pt_shade<false, true>), gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout, (uint32_t)(c->sort_out > (d > 0 ? 1 : 0)));
-            else hipLaunchKernelGGL((k_pt_shade<false, false>), gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout, (uint32_t)(c->sort_out > (d > 0 ? 1 : 0)));
+            if (d == 0) { if (regroup) hipLaunchKernelGGL((k_pt_shade<true, true>), gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
+                          else hipLaunchKernelGGL((k_pt_shade<true, false>), gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout); }
+            else if (regroup) hipLaunchKernelGGL((k_pt_shade<false, true>), gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
+            else hipLaunchKernelGGL((k_pt_shade<false, false>), gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
             std::swap(qin, qout);
         }
         if (!tail_done) mixed(st.max_bounces + 1u, qin);
