@@ -489,90 +489,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     }
 }
 
-// k_pt_shade<false, true> with four queue positions per thread: the workgroup sorts 1024 items by class instead of 256
-// (a class of the mixed scene then fills two waves and more instead of half a wave) and shades them in four rounds; wave
-// w takes the sorted items (4 r + w) * 64 .. + 63 in round r, so that every wave gets light and heavy classes alike.
-// The pushes of round r go where workgroup 4 b + r of the one-position kernel would send them.
-struct ShadeRegroupWide {
-    uint32_t slot[4 * kBlock], id[4 * kBlock]; float t[4 * kBlock], alpha[4 * kBlock], beta[4 * kBlock], gamma[4 * kBlock];
-    uint32_t count[4 * kBlock / 64][8], base[4 * kBlock / 64][8], total;
-};
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pt_shade_wide(WfPtrs w, DeviceScene sc, CameraDev cam, PassParams pp, const uint32_t* __restrict__ qin, uint32_t* qout)
-{
-    static_assert(kBlock == 256 && kClassCount <= 8, "sixteen groups of 64 items, eight counters each");
-    __shared__ ShadeRegroupWide s;
-    __shared__ StreamLens s_in;
-    const uint32_t extent = stream_load(w.cnt, pp.depth, s_in);
-    const uint32_t first = blockIdx.x * 4u * (uint32_t)kBlock;
-    if (first >= extent) return;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    {
-        bool have[4]; uint32_t slot[4], cls[4], rank[4]; rtx_hit h[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const uint32_t i = first + (uint32_t)r * kBlock + threadIdx.x;
-            have[r] = i < extent && stream_valid(s_in, i);
-            slot[r] = have[r] ? qin[i] : 0u;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            h[r].id = 0; h[r].t = FLT_MAX; h[r].alpha = h[r].beta = h[r].gamma = 0.0f;
-            if (have[r]) h[r] = w.hit[slot[r]];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            cls[r] = kClassMiss; rank[r] = 0;
-            if (have[r] && h[r].t < FLT_MAX) cls[r] = sc.shade[h[r].id].shade_class;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-#pragma unroll
-            for (uint32_t c = 0; c < 8u; c++) {
-                const unsigned long long m = __ballot(have[r] && cls[r] == c);
-                if (lane == c) s.count[r * 4 + wave][c] = (uint32_t)__popcll(m);
-                if (cls[r] == c) rank[r] = (uint32_t)__popcll(m & below);
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < 128u) {
-            const uint32_t g = threadIdx.x >> 3, c = threadIdx.x & 7u;
-            uint32_t b = 0;
-            for (uint32_t cc = 0; cc < c; cc++) for (uint32_t gg = 0; gg < 16u; gg++) b += s.count[gg][cc];
-            for (uint32_t gg = 0; gg < g; gg++) b += s.count[gg][c];
-            s.base[g][c] = b;
-            if (threadIdx.x == 127u) s.total = b + s.count[g][c];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            if (have[r]) {
-                const uint32_t p = s.base[r * 4 + wave][cls[r]] + rank[r];
-                s.slot[p] = slot[r]; s.id[p] = h[r].id; s.t[p] = h[r].t; s.alpha[p] = h[r].alpha; s.beta[p] = h[r].beta; s.gamma[p] = h[r].gamma;
-            }
-        }
-        __syncthreads();
-    }
-    const uint32_t total = s.total;
-    for (uint32_t r = 0; r < 4u; r++) {
-        const uint32_t p = (r * 4u + wave) * 64u + lane;
-        if ((r * 4u + wave) * 64u >= total) break;                       // (wave-uniform; later rounds of this wave lie further on)
-        const bool mine = p < total;
-        uint32_t slot = 0; rtx_hit h; h.id = 0; h.t = FLT_MAX; h.alpha = h.beta = h.gamma = 0.0f;
-        if (mine) { slot = s.slot[p]; h.id = s.id[p]; h.t = s.t[p]; h.alpha = s.alpha[p]; h.beta = s.beta[p]; h.gamma = s.gamma[p]; }
-        ShadeOut so; so.cont = so.shadow = false; so.sx = so.p2 = mk(0, 0, 0); so.sval = mkc(0, 0, 0);
-        if (mine) pt_shade_item<false>(w, sc, cam, pp, slot, h, so);
-        const uint32_t stream = (r << 2) | ((wave + blockIdx.x) & 3u);
-        const uint32_t qs = stream_push(so.shadow, w.cnt + stream_word(kShadowCounterBase + pp.depth, stream), stream);
-        if (so.shadow) {
-            float* sg = w.sseg + 6 * (size_t)qs; sg[0] = so.sx.x; sg[1] = so.sx.y; sg[2] = so.sx.z; sg[3] = so.p2.x; sg[4] = so.p2.y; sg[5] = so.p2.z;
-            st3(w.sval + 3 * (size_t)qs, so.sval); w.spath[qs] = slot;
-        }
-        const uint32_t qc = stream_push(so.cont, w.cnt + stream_word(pp.depth + 1, stream), stream);
-        if (so.cont) qout[qc] = slot;
-    }
-}
-
 // Shadow rays of one depth: a visible segment adds its value to the path's radiance
 // (Renderer.h:448-452, 463-469).
 struct ShadowAccumulatePolicy {
@@ -1603,7 +1519,6 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
             const bool regroup = d >= c->regroup_from_depth;
             if (d == 0) { if (regroup) hipLaunchKernelGGL((k_pt_shade<true, true>), gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
                           else hipLaunchKernelGGL((k_pt_shade<true, false>), gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout); }
-            else if (regroup && c->regroup_wide) hipLaunchKernelGGL(k_pt_shade_wide, dim3((w.P + 1023u) / 1024u), blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
             else if (regroup) hipLaunchKernelGGL((k_pt_shade<false, true>), gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
             else hipLaunchKernelGGL((k_pt_shade<false, false>), gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
             std::swap(qin, qout);
