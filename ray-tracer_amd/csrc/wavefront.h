@@ -61,6 +61,7 @@ struct WfPtrs {
     float* vpl;        // [V][10] x(3) n(3) Le(3) valid, slot j * (maxBounces + 1) + d of light path j
     float* vplc;       // [<= V][10] the valid ones, packed in list order
     uint32_t* vpl_total;
+    float* ir_bounds;  // [P / 256][12] boxes of the gather points and of their shading normals, per block of 256 places of the gather queue
     float* film; uint32_t* tile_samples;
     uint32_t* tile_off;   // [n_tiles] queue offset of the tile's first camera sample this pass
     uint32_t P, W, H, tiles_x, n_tiles, vpl_slots;
@@ -71,7 +72,7 @@ struct WfPtrs {
 };
 
 struct WavefrontBuffers {
-    DevBuf ray, hit, T, L, xy, key, dim, mis, flags, qa, qb, cnt, sseg, sval, sxy, spath, vpl, vpl_total, tile_off, ir_vis;
+    DevBuf ray, hit, T, L, xy, key, dim, mis, flags, qa, qb, cnt, sseg, sval, sxy, spath, vpl, vpl_total, tile_off, ir_vis, ir_bounds;
     WfPtrs p{};
     uint32_t vpl_capacity = 0;
     bool cnt_clean = false;      // the last pass on these buffers zeroed the counters itself when it was done with them (path tracing, box filter)
@@ -1129,6 +1130,63 @@ __global__ __launch_bounds__(kBlock) void k_ir_prepare(WfPtrs w, DeviceScene sc,
     }
 }
 
+// Box of the points and box of the shading normals of the places [256 b, 256 b + 256) of the gather queue (neighbouring
+// pixels mostly: a piece of one surface), for ir_block_culled. One workgroup per block; the launch covers every block
+// the film could have.
+__global__ __launch_bounds__(kBlock) void k_ir_bounds(WfPtrs w, int everything)
+{
+    static_assert(kBlock == 256, "one thread per place of a block");
+    const uint32_t ng = w.cnt[(1) * kQueueStride];
+    if (blockIdx.x * 256u >= ng) return;
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    float lo[6], hi[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) { lo[q] = FLT_MAX; hi[q] = -FLT_MAX; }
+    if (g < ng) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) lo[q] = hi[q] = w.sseg[6 * (size_t)g + q];
+    }
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+        for (int o = 32; o > 0; o >>= 1) { lo[q] = fminf(lo[q], __shfl_xor(lo[q], o, 64)); hi[q] = fmaxf(hi[q], __shfl_xor(hi[q], o, 64)); }
+    __shared__ float s_lo[kBlock / 64][6], s_hi[kBlock / 64][6];
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) { s_lo[wave][q] = lo[q]; s_hi[wave][q] = hi[q]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6u) {
+        const uint32_t q = threadIdx.x;
+        float l = s_lo[0][q], h = s_hi[0][q];
+        for (uint32_t wv = 1; wv < kBlock / 64; wv++) { l = fminf(l, s_lo[wv][q]); h = fmaxf(h, s_hi[wv][q]); }
+        if (everything) { l = -FLT_MAX; h = FLT_MAX; }      // (tuning switch: boxes that cull nothing)
+        // layout: point low, point high, normal low, normal high
+        float* out = w.ir_bounds + 12 * (size_t)blockIdx.x + (q < 3u ? q : q + 3u);
+        out[0] = l; out[3] = h;
+    }
+}
+
+// True when no place of a block can have a positive geometry term with the VPL at vx with normal vn: either the VPL
+// lies behind every point's surface or every point behind the VPL's. d = vx - x of every pair lies between vx - xhi
+// and vx - xlo component by component, as computed (rounding is monotone); interval bounds of the two dot products
+// follow. The margins are those of the pair test in k_ir_trace_packet with room for the roundings of the bounds
+// themselves: a pair of a block this returns true for fails that test too, so skipping the block changes no result.
+__device__ __forceinline__ bool ir_block_culled(const float* bb, V3 vx, V3 vn)
+{
+    const float vxc[3] = {vx.x, vx.y, vx.z}, vnc[3] = {vn.x, vn.y, vn.z};
+    float a_max = 0.0f, a_mag = 0.0f, b_min = 0.0f, b_mag = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const float dlo = vxc[q] - bb[3 + q], dhi = vxc[q] - bb[q], nlo = bb[6 + q], nhi = bb[9 + q];
+        const float dm = fmaxf(fabsf(dlo), fabsf(dhi));
+        a_max += fmaxf(fmaxf(dlo * nlo, dlo * nhi), fmaxf(dhi * nlo, dhi * nhi));
+        a_mag += dm * fmaxf(fabsf(nlo), fabsf(nhi));
+        b_min += fminf(dlo * vnc[q], dhi * vnc[q]);
+        b_mag += dm * fabsf(vnc[q]);
+    }
+    return a_max < -1e-5f * a_mag || b_min > 1e-5f * b_mag;
+}
+
 // geometry term between a gather point and a VPL, Renderer.h:229-236; wi comes back normalised
 __device__ __forceinline__ float ir_geometry(V3 x, V3 ns, V3 vx, V3 vn, V3& wi)
 {
@@ -1137,10 +1195,11 @@ __device__ __forceinline__ float ir_geometry(V3 x, V3 ns, V3 vx, V3 vn, V3& wi)
 }
 
 struct IrGatherPolicy {
-    const WfPtrs& w; uint32_t ng, v0; uint8_t* vis; unsigned long long* counters;
+    const WfPtrs& w; uint32_t ng, ngr, v0; uint8_t* vis; unsigned long long* counters;
     __device__ __forceinline__ bool fetch(uint32_t k, float o[3], float d[3], float& maxT) const
     {
-        const uint32_t vl = k / ng, g = k - vl * ng;
+        const uint32_t vl = k / ngr, g = k - vl * ngr;
+        if (g >= ng) { o[0] = o[1] = o[2] = 0.0f; d[0] = d[1] = d[2] = 0.0f; maxT = 0.0f; return false; }    // (padding of the last block)
         const float* v = w.vplc + 10 * (size_t)(v0 + vl); const float* r = w.sseg + 6 * (size_t)g;
         const V3 x = ld3(r), vx = ld3(v);
         V3 wi;
@@ -1164,9 +1223,10 @@ __global__ __launch_bounds__(kBlock) void k_ir_trace(WfPtrs w, DeviceScene sc, u
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
     const uint32_t ng = w.cnt[(1) * kQueueStride], total = *w.vpl_total;
     const uint32_t nv = total > v0 ? min(vb, total - v0) : 0u;
-    IrGatherPolicy pol{w, ng, v0, vis, counters};
+    const uint32_t ngr = (ng + 255u) & ~255u;
+    IrGatherPolicy pol{w, ng, ngr, v0, vis, counters};
     __shared__ TailShare<kBlock> ts;
-    traverse_dyn<IrGatherPolicy, kModeAny, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, COUNT ? 0 : kShare>(sc, stk, ng * nv, w.cnt + work_index, pol, counters, &ts);
+    traverse_dyn<IrGatherPolicy, kModeAny, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, COUNT ? 0 : kShare>(sc, stk, ngr * nv, w.cnt + work_index, pol, counters, &ts);
 }
 
 // k_ir_trace as one traversal per wave (traverse_packet.h): consecutive items are neighbouring pixels gathering from the
@@ -1178,14 +1238,15 @@ __global__ __launch_bounds__(kBlock) void k_ir_trace(WfPtrs w, DeviceScene sc, u
 __global__ __launch_bounds__(kBlock) void k_ir_trace_packet(WfPtrs w, DeviceScene sc, uint32_t v0, uint32_t vb, uint8_t* vis, uint32_t work_index, uint2* spill, uint32_t spill_stride
                                                             RTX_PACKET_STATS(, unsigned long long* stats))
 {
-    RTX_PACKET_STATS(uint32_t ws[6] = {0, 0, 0, 0, 0, 0};)
+    RTX_PACKET_STATS(uint32_t ws[7] = {0, 0, 0, 0, 0, 0, 0};)       // (tuning build: [0..3] packet_occluded's, [4] packets, [5] their segments, [6] blocks culled whole)
     __shared__ PacketStacks<kBlock> ps;
     __shared__ uint32_t s_ring[kBlock / 64][128];
     LaneStack<kBlock, 0> exact_stack; exact_stack.init(nullptr, spill, spill_stride);
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t ng = w.cnt[(1) * kQueueStride], total = *w.vpl_total;
     const uint32_t nv = total > v0 ? min(vb, total - v0) : 0u;
-    const uint32_t n = ng * nv, n_super = (n + 255u) / 256u;
+    const uint32_t ngr = (ng + 255u) & ~255u;       // a super-chunk is one block of 256 places for one VPL
+    const uint32_t n = ngr * nv, n_super = n / 256u;
     uint32_t* work = w.cnt + work_index;
     uint32_t seg = blockIdx.x % (uint32_t)kWorkSegments;
     unsigned long long dry = 0ull;                  // counters this wave has found empty
@@ -1207,15 +1268,16 @@ __global__ __launch_bounds__(kBlock) void k_ir_trace_packet(WfPtrs w, DeviceScen
                     do { seg = (seg + 1u) & (uint32_t)(kWorkSegments - 1); } while ((dry >> seg) & 1ull);
                     continue;
                 }
-                pair_next = g * 256u; pair_end = min(pair_next + 256u, n);
-                vl0 = pair_next / ng;
+                pair_next = g * 256u; pair_end = pair_next + 256u;
+                vl0 = pair_next / ngr;
+                // the whole block at once where its bounds allow it (nothing is written for its pairs: k_ir_shade decides the same)
+                const float* v = w.vplc + 10 * (size_t)(v0 + vl0);
+                if (ir_block_culled(w.ir_bounds + 12 * (size_t)((pair_next - vl0 * ngr) >> 8), ld3(v), ld3(v + 3))) { pair_next = pair_end; RTX_PACKET_STATS(ws[6]++;) continue; }
             }
             const uint32_t k = pair_next + lane;
             bool keep = false;
-            if (k < pair_end) {
-                // (all pairs of a super-chunk belong to VPL vl0 or the next one, when ng >= 256)
-                uint32_t vl = vl0, g = k - vl0 * ng;
-                if (g >= ng) { if (ng >= 256u) { vl++; g -= ng; } else { vl = k / ng; g = k - vl * ng; } }
+            if (k < pair_end && k - vl0 * ngr < ng) {
+                const uint32_t vl = vl0, g = k - vl0 * ngr;
                 const float* v = w.vplc + 10 * (size_t)(v0 + vl); const float* r = w.sseg + 6 * (size_t)g;
                 // A cheap test first: the geometry term (ir_geometry) is zero when the VPL lies behind the pixel's surface or
                 // the pixel behind the VPL's. The exact decision takes the NORMALISED direction (a square root and two
@@ -1244,7 +1306,7 @@ __global__ __launch_bounds__(kBlock) void k_ir_trace_packet(WfPtrs w, DeviceScen
         ring_head = (ring_head + take) & 127u; ring_count -= take;
         float o[3] = {0, 0, 0}, d[3] = {1, 1, 1}, maxT = 0.0f;
         if (has) {
-            const uint32_t vl = k / ng, g = k - vl * ng;
+            const uint32_t vl = k / ngr, g = k - vl * ngr;
             const float* v = w.vplc + 10 * (size_t)(v0 + vl); const float* r = w.sseg + 6 * (size_t)g;
             const V3 x = ld3(r), vx = ld3(v);
             V3 wi;
@@ -1257,7 +1319,7 @@ __global__ __launch_bounds__(kBlock) void k_ir_trace_packet(WfPtrs w, DeviceScen
         const bool blocked = packet_occluded<kBlock, false>(sc, ps, exact_stack, has, o[0], o[1], o[2], d[0], d[1], d[2], maxT, nullptr, nullptr RTX_PACKET_STATS(, stats ? ws : nullptr));
         if (has) vis[k] = blocked ? 0 : 1;
     }
-    RTX_PACKET_STATS(if (stats && lane == 0) for (int q = 0; q < 6; q++) atomicAdd(&stats[8 + q], (unsigned long long)ws[q]);)
+    RTX_PACKET_STATS(if (stats && lane == 0) for (int q = 0; q < 7; q++) atomicAdd(&stats[8 + q], (unsigned long long)ws[q]);)
 }
 
 // first: the sum starts at zero (otherwise it carries on from the launch before); last: divide by vpls.size(), Renderer.h:244
@@ -1265,29 +1327,52 @@ __global__ __launch_bounds__(kBlock) void k_ir_shade(WfPtrs w, DeviceScene sc, u
 {
     const uint32_t ng = w.cnt[(1) * kQueueStride], total = *w.vpl_total;
     const uint32_t nv = total > v0 ? min(vb, total - v0) : 0u;
-    for (uint32_t g = global_thread(); g < ng; g += gridDim.x * kBlock) {
-        const uint32_t slot = w.qb[g];
-        Shading sd;
-        sd.x = ld3(w.sseg + 6 * (size_t)g); sd.sNormal = ld3(w.sseg + 6 * (size_t)g + 3); sd.wo = ld3(w.T + 3 * (size_t)g);
-        sd.alb = ldc(w.sval + 3 * (size_t)g); sd.mat = &sc.materials[w.spath[g]];
+    const uint32_t ngr = (ng + 255u) & ~255u;
+    const uint32_t lane = threadIdx.x & 63u;
+    // a wave takes 64 consecutive places: they lie in one block of 256, and what k_ir_trace_packet skipped for the block
+    // as a whole (it wrote no result bytes there) is skipped here by the same test on the same numbers
+    for (uint32_t base = blockIdx.x * kBlock + (threadIdx.x & ~63u); base < ng; base += gridDim.x * kBlock) {
+        const uint32_t g = base + lane;
+        const bool act = g < ng;
+        const float* bb = w.ir_bounds + 12 * (size_t)(base >> 8);
+        uint32_t slot = 0; Shading sd; sd.mat = &sc.materials[0];
+        sd.x = sd.sNormal = sd.wo = mk(0, 0, 0); sd.alb = mkc(0, 0, 0);
+        if (act) {
+            slot = w.qb[g];
+            sd.x = ld3(w.sseg + 6 * (size_t)g); sd.sNormal = ld3(w.sseg + 6 * (size_t)g + 3); sd.wo = ld3(w.T + 3 * (size_t)g);
+            sd.alb = ldc(w.sval + 3 * (size_t)g); sd.mat = &sc.materials[w.spath[g]];
+        }
         sd.gNormal = sd.sNormal; sd.tu = sd.tv = 0.0f; sd.t = 0.0f;
         sd.frame.fromVector(sd.sNormal);
-        C3 acc = first ? mkc(0, 0, 0) : ldc(w.L + 3 * slot);
-        // eight result bytes at a time, so that their loads are in flight together (one dependent load per VPL otherwise)
-        for (uint32_t v8 = 0; v8 < nv; v8 += 8u) {
-            uint8_t flag[8];
+        C3 acc = (first || !act) ? mkc(0, 0, 0) : ldc(w.L + 3 * slot);
+        for (uint32_t v64 = 0; v64 < nv; v64 += 64u) {
+            // lane l decides for VPL v64 + l; the wave then walks the VPLs left, in list order
+            bool look = false;
+            if (v64 + lane < nv) { const float* v = w.vplc + 10 * (size_t)(v0 + v64 + lane); look = !ir_block_culled(bb, ld3(v), ld3(v + 3)); }
+            unsigned long long todo = __ballot(look);
+            while (todo != 0ull) {
+                // eight result bytes at a time, so that their loads are in flight together (one dependent load per VPL otherwise)
+                uint32_t idx[8]; uint8_t flag[8];
 #pragma unroll
-            for (uint32_t q = 0; q < 8u; q++) flag[q] = v8 + q < nv ? vis[(size_t)(v8 + q) * ng + g] : (uint8_t)0;
+                for (uint32_t q = 0; q < 8u; q++) {
+                    idx[q] = 0xFFFFFFFFu;
+                    if (todo != 0ull) { idx[q] = v64 + (uint32_t)__builtin_ctzll(todo); todo &= todo - 1ull; }
+                }
 #pragma unroll
-            for (uint32_t q = 0; q < 8u; q++) {
-                if (!flag[q]) continue;
-                const float* v = w.vplc + 10 * (size_t)(v0 + v8 + q);
-                V3 wi; const float gt = ir_geometry(sd.x, sd.sNormal, ld3(v), ld3(v + 3), wi);
-                acc = acc + bsdf_evaluate(sc, sd, wi) * ldc(v + 6) * gt;
+                for (uint32_t q = 0; q < 8u; q++) flag[q] = (act && idx[q] != 0xFFFFFFFFu) ? vis[(size_t)idx[q] * ngr + g] : (uint8_t)0;
+#pragma unroll
+                for (uint32_t q = 0; q < 8u; q++) {
+                    if (!flag[q]) continue;
+                    const float* v = w.vplc + 10 * (size_t)(v0 + idx[q]);
+                    V3 wi; const float gt = ir_geometry(sd.x, sd.sNormal, ld3(v), ld3(v + 3), wi);
+                    acc = acc + bsdf_evaluate(sc, sd, wi) * ldc(v + 6) * gt;
+                }
             }
         }
-        if (last) acc = acc / (float)total;
-        st3(w.L + 3 * slot, acc);
+        if (act) {
+            if (last) acc = acc / (float)total;
+            st3(w.L + 3 * slot, acc);
+        }
     }
 }
 
@@ -1349,13 +1434,14 @@ inline int wavefront_alloc(rtx_ctx* c, int lane, const rtx_settings& st)
     const size_t Q = P + kQueueSlack;      // what is indexed by queue position
     RTX_ENS(b.qa, Q * 4); RTX_ENS(b.qb, Q * 4); RTX_ENS(b.cnt, kCounterWords * 4);
     RTX_ENS(b.sseg, Q * 24); RTX_ENS(b.sval, Q * 12); RTX_ENS(b.sxy, P * 8); RTX_ENS(b.spath, Q * 4); RTX_ENS(b.vpl_total, 16); RTX_ENS(b.tile_off, P / 256 * 4);
+    if (st.algorithm == RTX_AL_INSTANT_RADIOSITY) RTX_ENS(b.ir_bounds, P / 256 * 48);
 #undef RTX_ENS
     WfPtrs& p = b.p;
     p.ray = b.ray.as<rtx_ray>(); p.hit = b.hit.as<rtx_hit>(); p.T = b.T.as<float>(); p.L = b.L.as<float>(); p.xy = b.xy.as<float>();
     p.key = b.key.as<uint32_t>(); p.dim = b.dim.as<uint32_t>(); p.mis = b.mis.as<float>(); p.flags = b.flags.as<uint32_t>();
     p.qa = b.qa.as<uint32_t>(); p.qb = b.qb.as<uint32_t>(); p.cnt = b.cnt.as<uint32_t>();
     p.sseg = b.sseg.as<float>(); p.sval = b.sval.as<float>(); p.sxy = b.sxy.as<float>(); p.spath = b.spath.as<uint32_t>();
-    p.vpl_total = b.vpl_total.as<uint32_t>(); p.tile_off = b.tile_off.as<uint32_t>();
+    p.vpl_total = b.vpl_total.as<uint32_t>(); p.tile_off = b.tile_off.as<uint32_t>(); p.ir_bounds = b.ir_bounds.as<float>();
     p.film = c->b_film.as<float>(); p.tile_samples = c->b_tile_samples.as<uint32_t>();
     p.P = (uint32_t)n_local * 256u; p.W = (uint32_t)c->cam.width; p.H = (uint32_t)c->cam.height; p.tiles_x = c->tiles_x; p.n_tiles = n_tiles;
     p.tile_mul = mul; p.tile_add = add; p.n_local_tiles = n_local;
@@ -1592,6 +1678,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
         closest_primary();
         hipLaunchKernelGGL(k_ir_prepare, gridQ, blk, 0, s, w, dscene, pp);
+        hipLaunchKernelGGL(k_ir_bounds, dim3(w.P / 256u), blk, 0, s, w, c->ir_block_cull ? 0 : 1);
         for (uint32_t bi = 0; bi < std::max(batches, 1u); bi++) {
             const uint32_t v0 = bi * vb, work = (uint32_t)(kShadowWorkBase + bi * kWorkSlotWords);
             uint8_t* vis = b.ir_vis.as<uint8_t>();

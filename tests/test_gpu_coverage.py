@@ -531,6 +531,27 @@ def test_tail_kernel_and_regrouping_leave_the_film_bit_identical(pkg, lib, lib_t
         np.testing.assert_allclose(f[~same], ref[~same], rtol=1e-5, atol=1e-6)
 
 
+def test_instant_radiosity_block_cull_leaves_the_film_bit_identical(pkg, lib, lib_tuning, scenes, monkeypatch):
+    """The gather skips a (block of 256 gather points, VPL) pair as a whole when the block's bounds say that no point of
+    it can have a positive geometry term with that VPL. That is a subset of what the pair-by-pair test rejects, so the
+    film must not change by a bit: shipped library against the tuning build with boxes that cull nothing. 640x360
+    mixed-material scene, 128 light paths per pass, three passes."""
+    scene, cam_kw = scenes.mixed_scene(48), scenes.mixed_camera()
+    st = pkg.make_settings(algorithm=pkg.AL_INSTANT_RADIOSITY, total_spp=1 << 20, max_bounces=5, vpl_rays_per_tile=16, num_threads=8, seed=5)
+    films = {}
+    for name, which, env in (("shipped", lib, {}), ("no block cull", lib_tuning, {"RTX_IR_BLOCK_CULL": "0"})):
+        monkeypatch.delenv("RTX_IR_BLOCK_CULL", raising=False)
+        for k, v in env.items(): monkeypatch.setenv(k, v)
+        c = pkg.Core(0, which)
+        c.upload_scene(scene); c.set_camera(pkg.look_at(which, width=640, height=360, **cam_kw)); c.set_settings(st); c.clear()
+        c.render_passes(3)
+        f, spp, _ = c.film()
+        assert spp == 3 and c.count_render_work(1)["vpls"] >= 64
+        films[name] = f
+        c.close()
+    assert np.array_equal(films["shipped"].view(np.uint32), films["no block cull"].view(np.uint32))
+
+
 # ---- a sample whose radiance is not a number is the reference's own result ---------------------
 
 def test_non_finite_sample_is_the_oracles(pkg, lib, core, orc, scenes):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Live paths and shadow segments per path depth of one 1080p pass of the mixed-material scene (tuning build:
-RTX_LIBRARY=tuning RTX_DEBUG_COUNTERS=1 python tools/pt_counts.py), printed on stderr by the library."""
+RTX_LIBRARY=tuning RTX_DEBUG_COUNTERS=1 python tools/pt_counts.py [algorithm]), printed on stderr by the library;
+algorithm 2 = instant radiosity with 128 light paths: packets of the gather and the blocks it skips whole."""
 import importlib
 import os
 import sys
@@ -15,6 +16,7 @@ lib = pkg.load_library()
 core = pkg.Core(0, lib)
 core.upload_scene(scenes.mixed_scene(128))
 core.set_camera(pkg.look_at(lib, width=1920, height=1080, **scenes.mixed_camera()))
-core.set_settings(pkg.make_settings(total_spp=100000, seed=1, use_mis=1, max_bounces=5))
+algorithm = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+core.set_settings(pkg.make_settings(total_spp=100000, seed=1, use_mis=1, max_bounces=5, algorithm=algorithm, num_threads=8, vpl_rays_per_tile=16))
 core.clear()
 print(core.count_render_work(1))
