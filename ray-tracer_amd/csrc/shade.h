@@ -403,54 +403,12 @@ RTX_DI int cdf_search_guided(const float* cdf, int n, const uint32_t* guide, flo
     while (left < right) { int mid = left + (right - left) / 2; if (cdf[mid] < value) left = mid + 1; else right = mid; }
     return left;
 }
-// cdf_search_guided, and the table's values at the index found (`at`) and just before it (`before`, when the index is
-// not 0): what tab_pdf reads. When the guide leaves at most eight candidates (nearly always: a bucket of the guide is
-// as likely as any other, and the buckets together cover the table twice) they are loaded in ONE round trip together
-// with their neighbours and the index is picked from registers: two dependent round trips per search (guide, window)
-// instead of the guide, a probe per halving and the two values. First index whose value is >= the argument, like the
-// halving search it replaces.
-RTX_DI int cdf_search_window(const float* cdf, int n, const uint32_t* guide, float value, float& at, float& before)
-{
-    int idx = -1;
-    if (guide[0] == 0xFFFFFFFFu) idx = cdf_search(cdf, n, value);
-    else if (value <= cdf[0]) idx = 0;
-    else if (value >= cdf[n - 1]) idx = n - 1;
-    else {
-        int b = (int)(value * (float)n);
-        b = b < 0 ? 0 : (b > n - 1 ? n - 1 : b);
-        int left = (int)guide[b - 2 < 0 ? 0 : b - 2], right = (int)guide[b + 3 > n ? n : b + 3];
-        if (right >= left && right - left <= 8) {
-            // entries left - 1 .. left + 8 (indices clamped to the table; a clamped entry is never the one picked)
-            float c[10];
-#pragma unroll
-            for (int q = 0; q < 10; q++) { int i = left - 1 + q; i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i); c[q] = cdf[i]; }
-            // no candidate below `right` reaches the value: the answer is `right` (<= left + 8, so inside the window)
-            const int r = right - left;
-            idx = right; at = c[1]; before = c[0];
-#pragma unroll
-            for (int q = 0; q < 9; q++) if (q == r) { at = c[q + 1]; before = c[q]; }
-#pragma unroll
-            for (int q = 7; q >= 0; q--) if (q < r && !(c[q + 1] < value)) { idx = left + q; at = c[q + 1]; before = c[q]; }
-            return idx;
-        }
-        while (left < right) { int mid = left + (right - left) / 2; if (cdf[mid] < value) left = mid + 1; else right = mid; }
-        idx = left;
-    }
-    at = cdf[idx]; before = idx == 0 ? 0.0f : cdf[idx - 1];
-    return idx;
-}
 template <class Sampler>
 RTX_DI V3 env_sample(const DeviceScene& sc, Sampler& rng, C3& emitted, float& pdf)    // Lights.h:252-277, 330-336
 {
-    float r_at, r_before, c_at, c_before;
-    unsigned row = cdf_search_window(sc.env_cdf_rows, sc.env_h, sc.env_guide_rows, rng.next(), r_at, r_before);
-    unsigned col = cdf_search_window(sc.env_cdf_cols + (size_t)row * sc.env_w, sc.env_w, sc.env_guide_cols + (size_t)row * (sc.env_w + 1), rng.next(), c_at, c_before);
-    {   // tab_pdf(sc, row, col) on the values the searches already hold
-        float mPDF = (row == 0) ? r_at : (r_at - r_before);
-        float cPDF = (col == 0) ? c_at : (c_at - c_before);
-        pdf = (mPDF * cPDF) * (float)((unsigned)sc.env_w * (unsigned)sc.env_h);
-        pdf = pdf < kEps ? kEps : pdf;
-    }
+    unsigned row = cdf_search_guided(sc.env_cdf_rows, sc.env_h, sc.env_guide_rows, rng.next());
+    unsigned col = cdf_search_guided(sc.env_cdf_cols + (size_t)row * sc.env_w, sc.env_w, sc.env_guide_cols + (size_t)row * (sc.env_w + 1), rng.next());
+    pdf = tab_pdf(sc, row, col);
     float u = (float)col * sc.env_inv_w;
     float v = (float)row * sc.env_inv_h;
     float phi = (float)(u * 2.0f * kPiD);
