@@ -175,6 +175,8 @@ def main():
     }
     only = args.only
     if rank == 0 and world == 1 and only in ("", "extras"):
+        # two launches in flight (a second context and stream): what the tail of a single 1080p launch costs
+        out["closest_two_launches_in_flight"] = closest_two_in_flight(pkg, lib, core, scene, cam, rays, hits, n, torch, dev, args, barrier)
         # the same kernel where the tail of a launch weighs less (4x the rays per launch) ...
         out["closest_soup_4k"] = closest_extra(pkg, lib, core, torch, dev, None, (0, 0, 3.5), (0, 0, 0), 45.0, 3840, 2160, args, prof, None, barrier)
         if not args.no_big:
@@ -281,6 +283,31 @@ def roofline(n, nodes, tris, groups, kernel_ms, prof, pmc_key):
         # no counter run of this launch is committed: only what this run measures
         r.update({"l1": {"lane_loads_16B_gbs": round(lanes, 1)}, "hbm": {"requested_at_cache_level_gbs": round(requested, 1)}})
     return r
+
+
+def closest_two_in_flight(pkg, lib, core, scene, cam, rays, hits, n, torch, dev, args, barrier):
+    """The headline launch with a second context tracing the same rays into a buffer of its own on its own stream,
+    launches alternating between the two: what a host that has independent batches gets when the end of one launch
+    (a few long rays, most lanes idle) overlaps the start of the next. Reported beside `value`, never as it:
+    `value` is one launch after the other on one stream."""
+    other = pkg.Core(torch.cuda.current_device(), lib)
+    other.upload_scene(scene)
+    other.set_camera(cam)
+    hits2 = torch.empty_like(hits)
+    cores, outs = (core, other), (hits, hits2)
+    for i in range(4):
+        cores[i & 1].trace_closest_device(rays.data_ptr(), n, outs[i & 1].data_ptr())
+    barrier()
+    steps = max(4, args.steps & ~1)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        cores[i & 1].trace_closest_device(rays.data_ptr(), n, outs[i & 1].data_ptr())
+    barrier()
+    dt = time.perf_counter() - t0
+    same = bool(torch.equal(hits, hits2))
+    other.close()
+    return {"mrays_per_s": round(n * steps / dt / 1e6, 1), "launches": steps, "ms_per_launch": round(dt / steps * 1e3, 4), "streams": 2,
+            "equal_hit_buffers": same}
 
 
 def closest_extra(pkg, lib, core, torch, dev, scene, frm, to, fov, width, height, args, prof, pmc_key, barrier):
