@@ -1684,7 +1684,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
             uint8_t* vis = b.ir_vis.as<uint8_t>();
             if (batches) {
                 if (cw) hipLaunchKernelGGL(k_ir_trace<true>, gridT, blk, 0, s, w, dscene, v0, vb, vis, work, spill, sstride, ctr);
-                else if (c->ir_packet && c->stack_need <= (uint32_t)kPacketStack) hipLaunchKernelGGL(k_ir_trace_packet, dim3(c->resident_packet_blocks), blk, 0, s, w, dscene, v0, vb, vis, work, spill, sstride RTX_PACKET_STATS(, c->b_counters.as<unsigned long long>()));
+                else if (c->ir_packet && c->stack_need <= (uint32_t)kPacketStack) hipLaunchKernelGGL(k_ir_trace_packet, dim3(c->resident_packet_blocks), blk, 0, s, w, dscene, v0, vb, vis, work, spill, sstride RTX_PACKET_STATS(, c->tail_stats ? c->b_counters.as<unsigned long long>() : nullptr));
                 else hipLaunchKernelGGL(k_ir_trace<false>, gridT, blk, 0, s, w, dscene, v0, vb, vis, work, spill, sstride, (unsigned long long*)nullptr);
             }
             hipLaunchKernelGGL(k_ir_shade, gridQ, blk, 0, s, w, dscene, v0, vb, (const uint8_t*)vis, bi == 0 ? 1 : 0, bi + 1u >= batches ? 1 : 0);
