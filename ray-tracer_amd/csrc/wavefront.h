@@ -625,7 +625,7 @@ struct PtTailPolicy {
 constexpr int kTailRefill = 8;       // idle lanes at which a wave takes more of its own items
 // ROUNDS: a wave's task is ROUNDS blocks of 64 queue positions; it shades them 64 at a time and walks all their rays in
 // one wave-local traversal (fuller lanes per trip, fewer waves resident: the lists take 4 KB of LDS per block).
-template <int ROUNDS, int HELP = kShare>
+template <int ROUNDS>
 __global__ __launch_bounds__(kBlock) void k_pt_tail(WfPtrs w, DeviceScene sc, CameraDev cam, PassParams pp, const uint32_t* __restrict__ qin, uint32_t task_index,
                                                     uint2* spill, uint32_t spill_stride RTX_PACKET_STATS(, unsigned long long* stats))
 {
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(kBlock) void k_pt_tail(WfPtrs w, DeviceScene sc, Ca
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             PtTailPolicy<64 * ROUNDS> pol{sc, w, t, n_live};
             RTX_PACKET_STATS(const unsigned long long c1 = stats ? wall_clock64() : 0ull;)
-            traverse_dyn<PtTailPolicy<64 * ROUNDS>, kModeMixed, false, kTailRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, HELP, true>(sc, stk, n_live + n_seg, nullptr, pol, nullptr, &ts);
+            traverse_dyn<PtTailPolicy<64 * ROUNDS>, kModeMixed, false, kTailRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare, true>(sc, stk, n_live + n_seg, nullptr, pol, nullptr, &ts);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             RTX_PACKET_STATS(if (stats) t_trace += wall_clock64() - c1;)
             if (n_live == 0u) break;                                   // the shadow rays of the paths' last vertices
@@ -1594,8 +1594,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
             if (d >= tail_from) {
                 mixed(d, qin);
                 RTX_PACKET_STATS(unsigned long long* stats = c->tail_stats ? c->b_counters.as<unsigned long long>() : nullptr;)
-                if (tail_rounds == 2 && !c->tail_help) hipLaunchKernelGGL((k_pt_tail<2, 0>), dim3(tail_blocks), blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, (uint32_t)kShadowWorkBase, spill, sstride RTX_PACKET_STATS(, stats));
-                else if (tail_rounds == 2) hipLaunchKernelGGL(k_pt_tail<2>, dim3(tail_blocks), blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, (uint32_t)kShadowWorkBase, spill, sstride RTX_PACKET_STATS(, stats));
+                if (tail_rounds == 2) hipLaunchKernelGGL(k_pt_tail<2>, dim3(tail_blocks), blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, (uint32_t)kShadowWorkBase, spill, sstride RTX_PACKET_STATS(, stats));
                 else hipLaunchKernelGGL(k_pt_tail<1>, dim3(tail_blocks), blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, (uint32_t)kShadowWorkBase, spill, sstride RTX_PACKET_STATS(, stats));
                 tail_done = true;
                 break;
