@@ -45,12 +45,11 @@ __device__ const uint32_t kInv16[17] = {0, 65536, 32768, 21846, 16384, 13108, 10
 // One segment per lane (has == false: the lane holds none). Returns true for lanes whose segment is NOT visible:
 // occluded, or the ray misses the root box (Geometry.h:571-572). All lanes of the wave must call this together.
 // COUNT: nodes / tris receive what the lane's own segment visited (the numbers a per-lane walk would count).
-// wave_stats (tuning builds, may be null): [0] node steps, [1] lanes in their masks, [2] triangle steps, [3] lanes in theirs,
-// [7] node steps with at most 16 lanes
+// wave_stats (tuning builds, may be null): [0] node steps, [1] lanes in their masks, [2] triangle steps, [3] lanes in theirs
 template <int BLOCK, bool COUNT>
 __device__ __forceinline__ bool packet_occluded(const DeviceScene& sc, PacketStacks<BLOCK>& ps, LaneStack<BLOCK, 0>& exact_stack, bool has,
                                                 float ox, float oy, float oz, float dx, float dy, float dz, float maxT, uint32_t* nodes, uint32_t* tris,
-                                                uint32_t* wave_stats = nullptr, int order = 0)
+                                                uint32_t* wave_stats = nullptr)
 {
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;                                    // Ray::init, Geometry.h:25
@@ -83,7 +82,7 @@ __device__ __forceinline__ bool packet_occluded(const DeviceScene& sc, PacketSta
             ConstFloat* np = nodes4 + (size_t)ref * 32;          // Node4: lo[axis][slot], hi[axis][slot], child[4]
             ConstWord* cp = (ConstWord*)(np + 24);
             if (COUNT && in) (*nodes)++;
-            if (wave_stats) { wave_stats[0]++; wave_stats[1] += (uint32_t)__popcll(mask); if (__popcll(mask) <= 16) wave_stats[7]++; }
+            if (wave_stats) { wave_stats[0]++; wave_stats[1] += (uint32_t)__popcll(mask); }
             const uint32_t cr[4] = {cp[0], cp[1], cp[2], cp[3]};
             if (one_way) {
                 ConstFloat* pnx = np + offx; ConstFloat* pny = np + offy; ConstFloat* pnz = np + offz;
@@ -94,25 +93,6 @@ __device__ __forceinline__ bool packet_occluded(const DeviceScene& sc, PacketSta
                 // behind the test of its child reference: four dependent round trips per node instead of one)
                 asm volatile("" :: "s"(nx[0]), "s"(nx[1]), "s"(nx[2]), "s"(nx[3]), "s"(ny[0]), "s"(ny[1]), "s"(ny[2]), "s"(ny[3]), "s"(nz[0]), "s"(nz[1]), "s"(nz[2]), "s"(nz[3]));
                 asm volatile("" :: "s"(fx[0]), "s"(fx[1]), "s"(fx[2]), "s"(fx[3]), "s"(fy[0]), "s"(fy[1]), "s"(fy[2]), "s"(fy[3]), "s"(fz[0]), "s"(fz[1]), "s"(fz[2]), "s"(fz[3]));
-                if (order != 0) {
-                    unsigned long long hm[4]; uint32_t key[4]; uint32_t crr[4] = {cr[0], cr[1], cr[2], cr[3]};
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        const float tentry = fmaxf(fmaxf((nx[c] - ox) * ix, (ny[c] - oy) * iy), (nz[c] - oz) * iz);
-                        const float texit = fminf(fminf((fx[c] - ox) * ix, (fy[c] - oy) * iy), (fz[c] - oz) * iz);
-                        const bool hit = in && !(tentry > texit || texit < 0) && !(tentry > bound);
-                        hm[c] = crr[c] == kEmptySlot ? 0ull : __ballot(hit);
-                        const int fl = hm[c] ? __builtin_ctzll(hm[c]) : 0;
-                        key[c] = hm[c] ? (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(fmaxf(tentry, 0.0f)), fl) : (order == 1 ? 0xFFFFFFFFu : 0u);
-                        if (order == 2 && hm[c]) key[c] = ~key[c];
-                    }
-#define RTX_PSWAP(a, b) { const bool sw = key[a] < key[b]; const uint32_t k0 = sw ? key[b] : key[a], k1 = sw ? key[a] : key[b]; const uint32_t r0 = sw ? crr[b] : crr[a], r1 = sw ? crr[a] : crr[b]; \
-                          const unsigned long long h0 = sw ? hm[b] : hm[a], h1 = sw ? hm[a] : hm[b]; key[a] = k0; key[b] = k1; crr[a] = r0; crr[b] = r1; hm[a] = h0; hm[b] = h1; }
-                    RTX_PSWAP(0, 1) RTX_PSWAP(2, 3) RTX_PSWAP(0, 2) RTX_PSWAP(1, 3) RTX_PSWAP(1, 2)      // descending keys: the smallest is popped first
-#undef RTX_PSWAP
-#pragma unroll
-                    for (int c = 0; c < 4; c++) if (hm[c] != 0ull) { s_ref[sp] = crr[c]; s_mask[sp] = hm[c]; sp++; }
-                } else {
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     if (cr[c] == kEmptySlot) continue;          // (wave-uniform)
@@ -121,7 +101,6 @@ __device__ __forceinline__ bool packet_occluded(const DeviceScene& sc, PacketSta
                     const bool hit = in && !(tentry > texit || texit < 0) && !(tentry > bound);
                     const unsigned long long hm = __ballot(hit);
                     if (hm != 0ull) { s_ref[sp] = cr[c]; s_mask[sp] = hm; sp++; }
-                }
                 }
             } else {
 #pragma unroll

@@ -1235,10 +1235,10 @@ __global__ __launch_bounds__(kBlock) void k_ir_trace(WfPtrs w, DeviceScene sc, u
 // sweeps the pairs on one front), evaluates the geometry term of 64 pairs at a time, marks the culled ones done and
 // collects the others in a small ring in LDS; whenever the ring holds a full wave of segments (or the pairs have
 // run out) it walks them as one packet. Same result bytes as k_ir_trace.
-__global__ __launch_bounds__(kBlock) void k_ir_trace_packet(WfPtrs w, DeviceScene sc, uint32_t v0, uint32_t vb, uint8_t* vis, uint32_t work_index, uint2* spill, uint32_t spill_stride, int order
+__global__ __launch_bounds__(kBlock) void k_ir_trace_packet(WfPtrs w, DeviceScene sc, uint32_t v0, uint32_t vb, uint8_t* vis, uint32_t work_index, uint2* spill, uint32_t spill_stride
                                                             RTX_PACKET_STATS(, unsigned long long* stats))
 {
-    RTX_PACKET_STATS(uint32_t ws[8] = {0, 0, 0, 0, 0, 0, 0, 0};)    // (tuning build: [0..3] and [7] packet_occluded's, [4] packets, [5] their segments, [6] blocks culled whole)
+    RTX_PACKET_STATS(uint32_t ws[7] = {0, 0, 0, 0, 0, 0, 0};)       // (tuning build: [0..3] packet_occluded's, [4] packets, [5] their segments, [6] blocks culled whole)
     __shared__ PacketStacks<kBlock> ps;
     __shared__ uint32_t s_ring[kBlock / 64][128];
     LaneStack<kBlock, 0> exact_stack; exact_stack.init(nullptr, spill, spill_stride);
@@ -1316,16 +1316,10 @@ __global__ __launch_bounds__(kBlock) void k_ir_trace_packet(WfPtrs w, DeviceScen
             } else { vis[k] = 0; has = false; }
         }
         RTX_PACKET_STATS(ws[4]++; ws[5] += take;)
-        const bool blocked = packet_occluded<kBlock, false>(sc, ps, exact_stack, has, o[0], o[1], o[2], d[0], d[1], d[2], maxT, nullptr, nullptr,
-#ifdef RTX_TUNING
-                                                             stats ? ws : nullptr,
-#else
-                                                             nullptr,
-#endif
-                                                             order);
+        const bool blocked = packet_occluded<kBlock, false>(sc, ps, exact_stack, has, o[0], o[1], o[2], d[0], d[1], d[2], maxT, nullptr, nullptr RTX_PACKET_STATS(, stats ? ws : nullptr));
         if (has) vis[k] = blocked ? 0 : 1;
     }
-    RTX_PACKET_STATS(if (stats && lane == 0) for (int q = 0; q < 8; q++) atomicAdd(&stats[8 + q], (unsigned long long)ws[q]);)
+    RTX_PACKET_STATS(if (stats && lane == 0) for (int q = 0; q < 7; q++) atomicAdd(&stats[8 + q], (unsigned long long)ws[q]);)
 }
 
 // first: the sum starts at zero (otherwise it carries on from the launch before); last: divide by vpls.size(), Renderer.h:244
@@ -1690,7 +1684,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
             uint8_t* vis = b.ir_vis.as<uint8_t>();
             if (batches) {
                 if (cw) hipLaunchKernelGGL(k_ir_trace<true>, gridT, blk, 0, s, w, dscene, v0, vb, vis, work, spill, sstride, ctr);
-                else if (c->ir_packet && c->stack_need <= (uint32_t)kPacketStack) hipLaunchKernelGGL(k_ir_trace_packet, dim3(c->resident_packet_blocks), blk, 0, s, w, dscene, v0, vb, vis, work, spill, sstride, c->ir_order RTX_PACKET_STATS(, c->tail_stats ? c->b_counters.as<unsigned long long>() : nullptr));
+                else if (c->ir_packet && c->stack_need <= (uint32_t)kPacketStack) hipLaunchKernelGGL(k_ir_trace_packet, dim3(c->resident_packet_blocks), blk, 0, s, w, dscene, v0, vb, vis, work, spill, sstride RTX_PACKET_STATS(, c->tail_stats ? c->b_counters.as<unsigned long long>() : nullptr));
                 else hipLaunchKernelGGL(k_ir_trace<false>, gridT, blk, 0, s, w, dscene, v0, vb, vis, work, spill, sstride, (unsigned long long*)nullptr);
             }
             hipLaunchKernelGGL(k_ir_shade, gridQ, blk, 0, s, w, dscene, v0, vb, (const uint8_t*)vis, bi == 0 ? 1 : 0, bi + 1u >= batches ? 1 : 0);
