@@ -825,7 +825,7 @@ int rtx_count_render_work(rtx_ctx* c, int n_passes, uint64_t out[8])
         int rc = wavefront_render_pass(c, 0, c->stream, nullptr, nullptr);
         if (rc) return fail(rc, "render pass failed");
         HIP_TRY(hipStreamSynchronize(c->stream));
-        unsigned long long p[7];
+        unsigned long long p[8];
         HIP_TRY(hipMemcpy(p, c->b_counters.as<unsigned long long>() + 8, sizeof p, hipMemcpyDeviceToHost));
         unsigned long long ts[8];
         HIP_TRY(hipMemcpy(ts, c->b_counters.as<unsigned long long>() + 16, sizeof ts, hipMemcpyDeviceToHost));
@@ -833,7 +833,7 @@ int rtx_count_render_work(rtx_ctx* c, int n_passes, uint64_t out[8])
                            ts[2], (double)ts[3] / ts[2], (double)ts[4] / ts[2], ts[0] / 100.0 / ts[2], ts[1] / 100.0 / ts[2], ts[5] / 100.0, ts[6] / 100.0, ts[7] / 100.0);
         if (p[4]) fprintf(stderr, "[rtx] packet walk: %llu packets of %.1f segments; per packet %.2f node steps with %.1f lanes, %.2f triangle steps with %.1f lanes\n", p[4], (double)p[5] / p[4],
                           (double)p[0] / p[4], p[0] ? (double)p[1] / p[0] : 0.0, (double)p[2] / p[4], p[2] ? (double)p[3] / p[2] : 0.0);
-        if (p[4]) fprintf(stderr, "[rtx] gather: %llu (block of 256 places, VPL) pairs culled whole\n", p[6]);
+        if (p[4]) fprintf(stderr, "[rtx] gather: %llu (block of 256 places, VPL) pairs culled whole; %llu of the node steps with at most 16 lanes\n", p[6], p[7]);
     }
 #endif
     return RTX_OK;

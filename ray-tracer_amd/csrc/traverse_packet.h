@@ -45,7 +45,8 @@ __device__ const uint32_t kInv16[17] = {0, 65536, 32768, 21846, 16384, 13108, 10
 // One segment per lane (has == false: the lane holds none). Returns true for lanes whose segment is NOT visible:
 // occluded, or the ray misses the root box (Geometry.h:571-572). All lanes of the wave must call this together.
 // COUNT: nodes / tris receive what the lane's own segment visited (the numbers a per-lane walk would count).
-// wave_stats (tuning builds, may be null): [0] node steps, [1] lanes in their masks, [2] triangle steps, [3] lanes in theirs
+// wave_stats (tuning builds, may be null): [0] node steps, [1] lanes in their masks, [2] triangle steps, [3] lanes in theirs,
+// [7] node steps with at most 16 lanes
 template <int BLOCK, bool COUNT>
 __device__ __forceinline__ bool packet_occluded(const DeviceScene& sc, PacketStacks<BLOCK>& ps, LaneStack<BLOCK, 0>& exact_stack, bool has,
                                                 float ox, float oy, float oz, float dx, float dy, float dz, float maxT, uint32_t* nodes, uint32_t* tris,
@@ -82,7 +83,7 @@ __device__ __forceinline__ bool packet_occluded(const DeviceScene& sc, PacketSta
             ConstFloat* np = nodes4 + (size_t)ref * 32;          // Node4: lo[axis][slot], hi[axis][slot], child[4]
             ConstWord* cp = (ConstWord*)(np + 24);
             if (COUNT && in) (*nodes)++;
-            if (wave_stats) { wave_stats[0]++; wave_stats[1] += (uint32_t)__popcll(mask); }
+            if (wave_stats) { wave_stats[0]++; wave_stats[1] += (uint32_t)__popcll(mask); if (__popcll(mask) <= 16) wave_stats[7]++; }
             const uint32_t cr[4] = {cp[0], cp[1], cp[2], cp[3]};
             if (one_way) {
                 ConstFloat* pnx = np + offx; ConstFloat* pny = np + offy; ConstFloat* pnz = np + offz;

@@ -1238,7 +1238,7 @@ __global__ __launch_bounds__(kBlock) void k_ir_trace(WfPtrs w, DeviceScene sc, u
 __global__ __launch_bounds__(kBlock) void k_ir_trace_packet(WfPtrs w, DeviceScene sc, uint32_t v0, uint32_t vb, uint8_t* vis, uint32_t work_index, uint2* spill, uint32_t spill_stride
                                                             RTX_PACKET_STATS(, unsigned long long* stats))
 {
-    RTX_PACKET_STATS(uint32_t ws[7] = {0, 0, 0, 0, 0, 0, 0};)       // (tuning build: [0..3] packet_occluded's, [4] packets, [5] their segments, [6] blocks culled whole)
+    RTX_PACKET_STATS(uint32_t ws[8] = {0, 0, 0, 0, 0, 0, 0, 0};)    // (tuning build: [0..3] and [7] packet_occluded's, [4] packets, [5] their segments, [6] blocks culled whole)
     __shared__ PacketStacks<kBlock> ps;
     __shared__ uint32_t s_ring[kBlock / 64][128];
     LaneStack<kBlock, 0> exact_stack; exact_stack.init(nullptr, spill, spill_stride);
@@ -1319,7 +1319,7 @@ __global__ __launch_bounds__(kBlock) void k_ir_trace_packet(WfPtrs w, DeviceScen
         const bool blocked = packet_occluded<kBlock, false>(sc, ps, exact_stack, has, o[0], o[1], o[2], d[0], d[1], d[2], maxT, nullptr, nullptr RTX_PACKET_STATS(, stats ? ws : nullptr));
         if (has) vis[k] = blocked ? 0 : 1;
     }
-    RTX_PACKET_STATS(if (stats && lane == 0) for (int q = 0; q < 7; q++) atomicAdd(&stats[8 + q], (unsigned long long)ws[q]);)
+    RTX_PACKET_STATS(if (stats && lane == 0) for (int q = 0; q < 8; q++) atomicAdd(&stats[8 + q], (unsigned long long)ws[q]);)
 }
 
 // first: the sum starts at zero (otherwise it carries on from the launch before); last: divide by vpls.size(), Renderer.h:244
