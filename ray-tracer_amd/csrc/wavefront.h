@@ -622,7 +622,7 @@ struct PtTailPolicy {
     }
     __device__ __forceinline__ void note(uint32_t, uint32_t, uint32_t) const {}
 };
-constexpr int kTailRefill = 16;      // idle lanes at which a wave takes more of its own items
+constexpr int kTailRefill = 8;       // idle lanes at which a wave takes more of its own items
 // ROUNDS: a wave's task is ROUNDS blocks of 64 queue positions; it shades them 64 at a time and walks all their rays in
 // one wave-local traversal (fuller lanes per trip, fewer waves resident: the lists take 4 KB of LDS per block).
 template <int ROUNDS>
