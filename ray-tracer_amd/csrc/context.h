@@ -97,7 +97,6 @@ struct rtx_ctx {
     int passes_in_flight = 1;                          // set by rtx_render_passes for the passes it is enqueueing
     int spill_lanes = 1;                               // traversal-stack slabs in b_spill
     hipStream_t pipe_stream[rtx::kPipeline] = {};
-    int merge_shadow = 1;                              // light tracing: the camera connections of a depth share a launch with the closest hits of the next (RTX_MERGE=0: separate launches)
     hipEvent_t pipe_film[rtx::kPipeline] = {}, pipe_done[rtx::kPipeline] = {}, ev_fork = nullptr, ev_tiles = nullptr;
 
     bool count_work = false;       // render passes run the instrumented traversal kernels (rtx_count_render_work)

@@ -230,7 +230,6 @@ static int create_resources(rtx_ctx* c, int device)
         HIP_TRY(hipEventCreateWithFlags(&c->pipe_film[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->pipe_done[i], hipEventDisableTiming));
     }
-    if (const char* v = tuning_env("RTX_MERGE")) c->merge_shadow = atoi(v) != 0;
     if (const char* v = tuning_env("RTX_RAYS_PER_BLOCK")) c->rays_per_block = std::max(1, std::min(kBlock, atoi(v)));
     if (const char* v = tuning_env("RTX_PIPELINE")) c->pipeline = std::max(1, std::min(kPipeline, atoi(v)));
     c->tail_stats = tuning_env("RTX_DEBUG_COUNTERS") != nullptr;

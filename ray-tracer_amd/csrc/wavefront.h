@@ -75,7 +75,7 @@ struct WavefrontBuffers {
     DevBuf ray, hit, T, L, xy, key, dim, mis, flags, qa, qb, cnt, sseg, sval, sxy, spath, vpl, vpl_total, tile_off, ir_vis, ir_bounds;
     WfPtrs p{};
     uint32_t vpl_capacity = 0;
-    bool cnt_clean = false;      // the last pass on these buffers zeroed the counters itself when it was done with them (path tracing, box filter)
+    bool cnt_clean = false;      // the last pass on these buffers zeroed the counters itself when it was done with them (path tracing with the box filter, light tracing)
 };
 
 struct PassParams {
@@ -861,9 +861,14 @@ __device__ __forceinline__ bool connect_request(const CameraDev& cam, V3 p, V3 n
     return true;
 }
 
-__device__ __forceinline__ void push_connection(const WfPtrs& w, bool want, uint32_t counter, V3 p, const CameraDev& cam, float x, float y, C3 value)
+// the stream the calling wave appends to (wave w of workgroup b: see k_pt_shade)
+__device__ __forceinline__ uint32_t wave_stream() { return ((blockIdx.x & 3u) << 2) | (((threadIdx.x >> 6) + (blockIdx.x >> 2)) & 3u); }
+
+// every lane of the wave calls this from uniform control flow (a streamed queue: one atomic per wave, no barrier)
+__device__ __forceinline__ void push_connection(const WfPtrs& w, bool want, uint32_t queue, V3 p, const CameraDev& cam, float x, float y, C3 value)
 {
-    uint32_t qs = queue_slot(want, &w.cnt[(counter) * kQueueStride]);
+    const uint32_t stream = wave_stream();
+    const uint32_t qs = stream_push(want, w.cnt + stream_word(queue, stream), stream);
     if (want) {
         float* s = w.sseg + 6 * (size_t)qs; s[0] = p.x; s[1] = p.y; s[2] = p.z; s[3] = cam.origin[0]; s[4] = cam.origin[1]; s[5] = cam.origin[2];
         st3(w.sval + 3 * (size_t)qs, value); w.sxy[2 * (size_t)qs] = x; w.sxy[2 * (size_t)qs + 1] = y;
@@ -899,19 +904,22 @@ __global__ __launch_bounds__(kBlock) void k_lt_emit(WfPtrs w, DeviceScene sc, Ca
     push_connection(w, conn, kShadowCounterBase + 95, p, cam, fx, fy, cval);
     // lightTracePath returns at once when maxBounces == 0 (Renderer.h:339)
     bool live = active && pp.st.max_bounces > 0;
-    uint32_t q = queue_slot(live, &w.cnt[(0) * kQueueStride]);
+    const uint32_t stream = wave_stream();
+    const uint32_t q = stream_push(live, w.cnt + stream_word(0u, stream), stream);
     if (live) w.qa[q] = slot;
 }
 
 // One depth of RayTracer::lightTracePath, RTBase/Renderer.h:336-377
+// (one queue position per thread; the launch covers every position the queue can have, workgroups beyond its end leave at once)
 __global__ __launch_bounds__(kBlock) void k_lt_shade(WfPtrs w, DeviceScene sc, CameraDev cam, PassParams pp, const uint32_t* __restrict__ qin, uint32_t* qout)
 {
-    const uint32_t n = w.cnt[(pp.depth) * kQueueStride];
-    const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
-    for (uint32_t it = 0; it < rounds; it++) {
-        const uint32_t i = it * gridDim.x * kBlock + global_thread();
+    __shared__ StreamLens s_in;
+    const uint32_t extent = stream_load(w.cnt, pp.depth, s_in);
+    if (blockIdx.x * (uint32_t)kBlock >= extent) return;
+    {
+        const uint32_t i = global_thread();
         bool cont = false, conn = false; uint32_t slot = 0; V3 hp = mk(0, 0, 0); float fx = 0, fy = 0; C3 cval = mkc(0, 0, 0);
-        if (i < n) {
+        if (i < extent && stream_valid(s_in, i)) {
             slot = qin[i];
             const rtx_hit h = w.hit[slot]; const rtx_ray r = w.ray[slot];
             if (h.t < FLT_MAX) {
@@ -937,40 +945,62 @@ __global__ __launch_bounds__(kBlock) void k_lt_shade(WfPtrs w, DeviceScene sc, C
             }
         }
         push_connection(w, conn, kShadowCounterBase + pp.depth, hp, cam, fx, fy, cval);
-        uint32_t qc = queue_slot(cont, &w.cnt[(pp.depth + 1) * kQueueStride]);
+        const uint32_t stream = wave_stream();
+        const uint32_t qc = stream_push(cont, w.cnt + stream_word(pp.depth + 1, stream), stream);
         if (cont) qout[qc] = slot;
     }
 }
 
 // Camera connections of one stage: visible ones splat onto the film (Renderer.h:325-331)
 struct SplatPolicy {
-    const WfPtrs& w; int filter;
-    __device__ __forceinline__ bool fetch(uint32_t k, float o[3], float d[3], float& maxT) const { segment_to_ray(w.sseg + 6 * (size_t)k, o, d, maxT); return true; }
+    const WfPtrs& w; int filter; const StreamLens& segs;
+    __device__ __forceinline__ bool fetch(uint32_t k, float o[3], float d[3], float& maxT) const
+    {
+        if (!stream_valid(segs, k)) { o[0] = o[1] = o[2] = 0.0f; d[0] = d[1] = d[2] = 0.0f; maxT = 0.0f; return false; }    // a hole of the streamed queue
+        segment_to_ray(w.sseg + 6 * (size_t)k, o, d, maxT); return true;
+    }
     __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool reached) const
     {
         if (reached && best.pos == 0xFFFFFFFFu)
             film_splat(w.film, (int)w.W, (int)w.H, filter, w.sxy[2 * (size_t)k], w.sxy[2 * (size_t)k + 1], ldc(w.sval + 3 * (size_t)k));
     }
 };
-__global__ __launch_bounds__(kBlock) void k_lt_splat(WfPtrs w, DeviceScene sc, uint32_t counter_index, uint32_t work_index, int filter, uint2* spill, uint32_t spill_stride)
+__global__ __launch_bounds__(kBlock) void k_lt_splat(WfPtrs w, DeviceScene sc, uint32_t queue_index, uint32_t work_index, int filter, uint2* spill, uint32_t spill_stride)
 {
     __shared__ unsigned long long lds[kBlock * kLdsStack];
+    __shared__ StreamLens s_segs;
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
-    SplatPolicy pol{w, filter};
+    const uint32_t n = stream_load(w.cnt, queue_index, s_segs);
+    SplatPolicy pol{w, filter, s_segs};
     __shared__ TailShare<kBlock> ts;
-    traverse_dyn<SplatPolicy, kModeAny, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, w.cnt[(counter_index) * kQueueStride], w.cnt + work_index, pol, nullptr, &ts);
+    traverse_dyn<SplatPolicy, kModeAny, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, n, w.cnt + work_index, pol, nullptr, &ts);
+}
+
+// The counters of a finished pass back to zero, as the next pass on these buffers expects them: a launch at the end of the
+// pass instead of a memset at the start of the next (a memset takes the host several times longer to enqueue than a
+// kernel, which a caller that asks for one pass per call waits for).
+__global__ __launch_bounds__(kBlock) void k_zero_counters(WfPtrs w)
+{
+    for (uint32_t i = global_thread(); i < (uint32_t)kCounterWords; i += gridDim.x * (uint32_t)kBlock) w.cnt[i] = 0u;
 }
 
 // The camera connections of one stage and the closest hits of the next in one launch (as k_pt_trace_mixed does for the
 // path tracer's shadow rays): items [0, n_closest) are the live light paths of `queue`, the others connection segments.
 struct LtMixedPolicy {
-    const DeviceScene& sc; const WfPtrs& w; const uint32_t* queue; uint32_t n_closest; int filter;
+    const DeviceScene& sc; const WfPtrs& w; const uint32_t* queue; uint32_t n_closest; int filter; const StreamLens& live; const StreamLens& segs;
     __device__ __forceinline__ bool fetch(uint32_t k, float o[3], float d[3], float& maxT, bool& any) const
     {
+        o[0] = o[1] = o[2] = 0.0f; d[0] = d[1] = d[2] = 0.0f; maxT = 0.0f;
         if (k < n_closest) {
+            any = false;
+            if (!stream_valid(live, k)) return false;              // a hole of the streamed queue
             const rtx_ray r = w.ray[queue[k]];
-            o[0] = r.o[0]; o[1] = r.o[1]; o[2] = r.o[2]; d[0] = r.d[0]; d[1] = r.d[1]; d[2] = r.d[2]; maxT = 0.0f; any = false;
-        } else { segment_to_ray(w.sseg + 6 * (size_t)(k - n_closest), o, d, maxT); any = true; }
+            o[0] = r.o[0]; o[1] = r.o[1]; o[2] = r.o[2]; d[0] = r.d[0]; d[1] = r.d[1]; d[2] = r.d[2];
+        } else {
+            any = true;
+            if (!stream_valid(segs, k - n_closest)) return false;
+            segment_to_ray(w.sseg + 6 * (size_t)(k - n_closest), o, d, maxT);
+        }
         return true;
     }
     __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool reached) const
@@ -983,15 +1013,18 @@ struct LtMixedPolicy {
     }
     __device__ __forceinline__ void note(uint32_t, uint32_t, uint32_t) const {}
 };
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_lt_trace_mixed(WfPtrs w, DeviceScene sc, uint32_t closest_counter, uint32_t segment_counter,
-                                                           const uint32_t* __restrict__ queue, uint32_t work_index, int filter, uint2* spill, uint32_t spill_stride)
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_lt_trace_mixed(WfPtrs w, DeviceScene sc, uint32_t live_queue, uint32_t segment_queue,
+                                                           const uint32_t* __restrict__ queue, uint32_t work_index, int filter, uint2* spill, uint32_t spill_stride,
+                                                           unsigned long long* counters)
 {
     __shared__ unsigned long long lds[kBlock * kLdsStack];
+    __shared__ StreamLens s_live, s_segs;
     LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
-    const uint32_t n_closest = w.cnt[(closest_counter) * kQueueStride], n_seg = w.cnt[(segment_counter) * kQueueStride];
-    LtMixedPolicy pol{sc, w, queue, n_closest, filter};
+    const uint32_t n_closest = stream_load(w.cnt, live_queue, s_live), n_seg = stream_load(w.cnt, segment_queue, s_segs);
+    LtMixedPolicy pol{sc, w, queue, n_closest, filter, s_live, s_segs};
     __shared__ TailShare<kBlock> ts;
-    traverse_dyn<LtMixedPolicy, kModeMixed, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, n_closest + n_seg, w.cnt + work_index, pol, nullptr, &ts);
+    traverse_dyn<LtMixedPolicy, kModeMixed, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, COUNT ? 0 : kShare>(sc, stk, n_closest + n_seg, w.cnt + work_index, pol, counters, &ts);
 }
 
 // ---- instant radiosity: RTBase/Renderer.h:124-302 -------------------------------------------
@@ -1433,7 +1466,7 @@ inline int wavefront_alloc(rtx_ctx* c, int lane, const rtx_settings& st)
     RTX_ENS(b.xy, P * 8); RTX_ENS(b.key, P * 4); RTX_ENS(b.dim, P * 4); RTX_ENS(b.mis, P * 4); RTX_ENS(b.flags, P * 4);
     const size_t Q = P + kQueueSlack;      // what is indexed by queue position
     RTX_ENS(b.qa, Q * 4); RTX_ENS(b.qb, Q * 4); RTX_ENS(b.cnt, kCounterWords * 4);
-    RTX_ENS(b.sseg, Q * 24); RTX_ENS(b.sval, Q * 12); RTX_ENS(b.sxy, P * 8); RTX_ENS(b.spath, Q * 4); RTX_ENS(b.vpl_total, 16); RTX_ENS(b.tile_off, P / 256 * 4);
+    RTX_ENS(b.sseg, Q * 24); RTX_ENS(b.sval, Q * 12); RTX_ENS(b.sxy, Q * 8); RTX_ENS(b.spath, Q * 4); RTX_ENS(b.vpl_total, 16); RTX_ENS(b.tile_off, P / 256 * 4);
     if (st.algorithm == RTX_AL_INSTANT_RADIOSITY) RTX_ENS(b.ir_bounds, P / 256 * 48);
 #undef RTX_ENS
     WfPtrs& p = b.p;
@@ -1620,28 +1653,21 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
     } else if (st.algorithm == RTX_AL_LIGHT_TRACE) {
         hipLaunchKernelGGL(k_lt_emit, gridP, blk, 0, s, w, dscene, c->dcam, pp);
         uint32_t* qin = w.qa; uint32_t* qout = w.qb;
-        if (c->merge_shadow && !cw && st.max_bounces > 0) {
-            // the connections of the light vertices ride with the closest hits of depth 0, those of depth d with the
-            // closest hits of depth d + 1; the last ones go alone
-            for (uint32_t d = 0; d < st.max_bounces; d++) {
-                pp.depth = d;
-                hipLaunchKernelGGL(k_lt_trace_mixed, gridT, blk, 0, s, w, dscene, d, (uint32_t)(kShadowCounterBase + (d == 0 ? 95u : d - 1u)), (const uint32_t*)qin,
-                                   (uint32_t)(kClosestWorkBase + d * kWorkSlotWords), (int)st.filter, spill, sstride);
-                hipLaunchKernelGGL(k_lt_shade, gridQ, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
-                std::swap(qin, qout);
-            }
-            const uint32_t last = st.max_bounces - 1u;
-            hipLaunchKernelGGL(k_lt_splat, gridT, blk, 0, s, w, dscene, (uint32_t)(kShadowCounterBase + last), (uint32_t)(kShadowWorkBase + last * kWorkSlotWords), (int)st.filter, spill, sstride);
-        } else {
-            hipLaunchKernelGGL(k_lt_splat, gridT, blk, 0, s, w, dscene, (uint32_t)(kShadowCounterBase + 95), (uint32_t)(kShadowWorkBase + 95 * kWorkSlotWords), (int)st.filter, spill, sstride);
-            for (uint32_t d = 0; d < st.max_bounces; d++) {
-                pp.depth = d;
-                closest(qin, d);
-                hipLaunchKernelGGL(k_lt_shade, gridQ, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
-                hipLaunchKernelGGL(k_lt_splat, gridT, blk, 0, s, w, dscene, (uint32_t)(kShadowCounterBase + d), (uint32_t)(kShadowWorkBase + d * kWorkSlotWords), (int)st.filter, spill, sstride);
-                std::swap(qin, qout);
-            }
+        const dim3 gridS((w.P + 1023u) / 1024u * 4u);       // a thread for every position a streamed queue can have
+        // the connections of the light vertices (queue 95) ride with the closest hits of depth 0, those of depth d with the
+        // closest hits of depth d + 1; the last ones go alone
+        for (uint32_t d = 0; d < st.max_bounces; d++) {
+            pp.depth = d;
+            const uint32_t seg_q = (uint32_t)kShadowCounterBase + (d == 0 ? 95u : d - 1u), work = (uint32_t)(kClosestWorkBase + d * kWorkSlotWords);
+            if (cw) hipLaunchKernelGGL(k_lt_trace_mixed<true>, gridT, blk, 0, s, w, dscene, d, seg_q, (const uint32_t*)qin, work, (int)st.filter, spill, sstride, ctr);
+            else hipLaunchKernelGGL(k_lt_trace_mixed<false>, gridT, blk, 0, s, w, dscene, d, seg_q, (const uint32_t*)qin, work, (int)st.filter, spill, sstride, (unsigned long long*)nullptr);
+            hipLaunchKernelGGL(k_lt_shade, gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
+            std::swap(qin, qout);
         }
+        const uint32_t last = st.max_bounces > 0 ? st.max_bounces - 1u : 95u;
+        hipLaunchKernelGGL(k_lt_splat, gridT, blk, 0, s, w, dscene, (uint32_t)(kShadowCounterBase + last), (uint32_t)(kShadowWorkBase + last * kWorkSlotWords), (int)st.filter, spill, sstride);
+        // (the instrumented passes leave their counters for the caller to read)
+        if (!cw) { hipLaunchKernelGGL(k_zero_counters, dim3(64), blk, 0, s, w); b.cnt_clean = true; }
         c->stats.samples += (uint64_t)w.W * w.H;
     } else {
         // radiosityVplPass, RTBase/Renderer.h:280-302: numThreads x vplRaysPerTile light paths
