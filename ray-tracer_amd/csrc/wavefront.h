@@ -75,7 +75,7 @@ struct WavefrontBuffers {
     DevBuf ray, hit, T, L, xy, key, dim, mis, flags, qa, qb, cnt, sseg, sval, sxy, spath, vpl, vpl_total, tile_off, ir_vis, ir_bounds;
     WfPtrs p{};
     uint32_t vpl_capacity = 0;
-    bool cnt_clean = false;      // the last pass on these buffers zeroed the counters itself when it was done with them (path tracing with the box filter, light tracing)
+    bool cnt_clean = false;      // the last pass on these buffers zeroed the counters itself when it was done with them (path tracing, box filter)
 };
 
 struct PassParams {
@@ -976,14 +976,6 @@ __global__ __launch_bounds__(kBlock) void k_lt_splat(WfPtrs w, DeviceScene sc, u
     traverse_dyn<SplatPolicy, kModeAny, false, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare>(sc, stk, n, w.cnt + work_index, pol, nullptr, &ts);
 }
 
-// The counters of a finished pass back to zero, as the next pass on these buffers expects them: a launch at the end of the
-// pass instead of a memset at the start of the next (a memset takes the host several times longer to enqueue than a
-// kernel, which a caller that asks for one pass per call waits for).
-__global__ __launch_bounds__(kBlock) void k_zero_counters(WfPtrs w)
-{
-    for (uint32_t i = global_thread(); i < (uint32_t)kCounterWords; i += gridDim.x * (uint32_t)kBlock) w.cnt[i] = 0u;
-}
-
 // The camera connections of one stage and the closest hits of the next in one launch (as k_pt_trace_mixed does for the
 // path tracer's shadow rays): items [0, n_closest) are the live light paths of `queue`, the others connection segments.
 struct LtMixedPolicy {
@@ -1666,8 +1658,6 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         }
         const uint32_t last = st.max_bounces > 0 ? st.max_bounces - 1u : 95u;
         hipLaunchKernelGGL(k_lt_splat, gridT, blk, 0, s, w, dscene, (uint32_t)(kShadowCounterBase + last), (uint32_t)(kShadowWorkBase + last * kWorkSlotWords), (int)st.filter, spill, sstride);
-        // (the instrumented passes leave their counters for the caller to read)
-        if (!cw) { hipLaunchKernelGGL(k_zero_counters, dim3(64), blk, 0, s, w); b.cnt_clean = true; }
         c->stats.samples += (uint64_t)w.W * w.H;
     } else {
         // radiosityVplPass, RTBase/Renderer.h:280-302: numThreads x vplRaysPerTile light paths
