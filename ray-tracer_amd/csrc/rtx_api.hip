@@ -225,21 +225,8 @@ static int create_resources(rtx_ctx* c, int device)
     HIP_TRY(hipEventCreate(&c->ev1));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_tiles, hipEventDisableTiming));
-    // The passes in flight only overlap if their streams sit on different hardware queues. The runtime keeps a few
-    // queues per process and stream priority (four by default) and hands a new stream the least used one of its
-    // priority, so with streams of the default priority the outcome depends on every other stream the process has made
-    // (the framework's, other libraries', earlier contexts'): the second context of a process had two of its three lanes
-    // on one queue and rendered 16 % slower than the first. The lanes' streams are therefore all made with a priority
-    // other than the default, one after the other: that set of queues is the renderer's own in practice, a context
-    // adds one stream to each of its queues, and lanes never share one.
-    int prio_least = 0, prio_greatest = 0;
-    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    // (the greatest priority, not the least: lanes of the least priority never got to run beside the caller's stream in a trial)
-    bool lane_priority = true;                           // RTX_LANE_PRIORITY=0: streams of the default priority
-    if (const char* v = tuning_env("RTX_LANE_PRIORITY")) lane_priority = atoi(v) != 0;
     for (int i = 0; i < kPipeline; i++) {
-        if (lane_priority && prio_least != prio_greatest) HIP_TRY(hipStreamCreateWithPriority(&c->pipe_stream[i], hipStreamNonBlocking, prio_greatest));
-        else HIP_TRY(hipStreamCreateWithFlags(&c->pipe_stream[i], hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&c->pipe_stream[i], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&c->pipe_film[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->pipe_done[i], hipEventDisableTiming));
     }
@@ -450,11 +437,11 @@ int rtx_render_passes(rtx_ctx* c, int n)
         return RTX_OK;
     }
     if (c->spill_lanes < lanes) { c->spill_lanes = lanes; int rc = ensure_spill(c); if (rc) return rc; }
-    // every lane on a stream of the context's own (see rtx_create); the caller's stream forks them and joins them
+    // lane 0 runs on the caller's stream itself, the others on streams of their own
     hipStream_t ls[kPipeline];
-    for (int l = 0; l < lanes; l++) ls[l] = c->pipe_stream[l];
+    for (int l = 0; l < lanes; l++) ls[l] = l == 0 ? c->stream : c->pipe_stream[l];
     HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
-    for (int l = 0; l < lanes; l++) HIP_TRY(hipStreamWaitEvent(ls[l], c->ev_fork, 0));
+    for (int l = 1; l < lanes; l++) HIP_TRY(hipStreamWaitEvent(ls[l], c->ev_fork, 0));
     const rtx_settings& st = c->settings;
     // an error in the middle leaves passes enqueued on the other lanes: nothing returns before they have drained
     auto drain = [&]() { for (int l = 0; l < lanes; l++) (void)hipStreamSynchronize(ls[l]); };
@@ -469,7 +456,7 @@ int rtx_render_passes(rtx_ctx* c, int n)
             for (int k = 0; k < lanes; k++) if (k != l) RTX_PIPE_TRY(hipStreamWaitEvent(ls[k], c->ev_tiles, 0));
         }
     }
-    for (int l = 0; l < lanes; l++) {
+    for (int l = 1; l < lanes; l++) {
         RTX_PIPE_TRY(hipEventRecord(c->pipe_done[l], ls[l]));
         RTX_PIPE_TRY(hipStreamWaitEvent(c->stream, c->pipe_done[l], 0));
     }
