@@ -226,7 +226,8 @@ static int create_resources(rtx_ctx* c, int device)
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_tiles, hipEventDisableTiming));
     for (int i = 0; i < kPipeline; i++) {
-        HIP_TRY(hipStreamCreateWithFlags(&c->pipe_stream[i], hipStreamNonBlocking));
+        // (lane 0 runs on the caller's stream: no stream of its own; lanes beyond the third get theirs when they are first used)
+        if (i == 1 || i == 2) HIP_TRY(hipStreamCreateWithFlags(&c->pipe_stream[i], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&c->pipe_film[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->pipe_done[i], hipEventDisableTiming));
     }
@@ -439,6 +440,7 @@ int rtx_render_passes(rtx_ctx* c, int n)
     if (c->spill_lanes < lanes) { c->spill_lanes = lanes; int rc = ensure_spill(c); if (rc) return rc; }
     // lane 0 runs on the caller's stream itself, the others on streams of their own
     hipStream_t ls[kPipeline];
+    for (int l = 1; l < lanes; l++) if (!c->pipe_stream[l]) HIP_TRY(hipStreamCreateWithFlags(&c->pipe_stream[l], hipStreamNonBlocking));
     for (int l = 0; l < lanes; l++) ls[l] = l == 0 ? c->stream : c->pipe_stream[l];
     HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
     for (int l = 1; l < lanes; l++) HIP_TRY(hipStreamWaitEvent(ls[l], c->ev_fork, 0));
