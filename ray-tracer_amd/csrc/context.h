@@ -86,7 +86,7 @@ struct rtx_ctx {
     int spp = 0;
     uint32_t tiles_x = 0, tiles_y = 0;
     rtx::WavefrontBuffers* wf[rtx::kPipeline] = {};   // path state of the passes in flight; [0] always exists once a camera is set
-    int pipeline = 3;                                  // passes rtx_render_passes keeps in flight (RTX_PIPELINE); 3 + the caller's stream fit the 4 hardware queues
+    int pipeline = 0;                                  // passes rtx_render_passes keeps in flight: 0 = three, four for a small film or share of one (RTX_PIPELINE fixes it); a process has 4 hardware queues
     uint32_t tail_from_depth = 1;                      // path tracing: not before this depth one launch carries every path to its end (k_pt_tail); 0: never (RTX_TAIL_FROM)
     uint32_t* depth_stats = nullptr;                   // pinned host memory the path tracer's last kernel reports its queue sizes per depth to (see publish_depth_stats)
     bool ir_block_cull = true;                         // instant radiosity: (block of 256 gather points, VPL) pairs are skipped whole where their bounds allow it (RTX_IR_BLOCK_CULL)
