@@ -214,8 +214,6 @@ static int create_resources(rtx_ctx* c, int device)
         c->resident_tail_blocks[0] = std::max(1, std::min(kMaxGridBlocks, per_cu * prop.multiProcessorCount));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pt_tail<2>, kBlock, 0));
         c->resident_tail_blocks[1] = std::max(1, std::min(kMaxGridBlocks, per_cu * prop.multiProcessorCount));
-        { int pc = 0; HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_lt_tail, kBlock, 0)); c->resident_lt_tail_blocks = std::max(1, std::min(kMaxGridBlocks, pc * prop.multiProcessorCount)); }
-        if (const char* v = tuning_env("RTX_LT_TAIL_FROM")) c->lt_tail_from = (uint32_t)std::max(0, atoi(v));
         if (const char* v = tuning_env("RTX_IR_PACKET")) c->ir_packet = atoi(v);
         if (const char* v = tuning_env("RTX_IR_BLOCK_CULL")) c->ir_block_cull = atoi(v) != 0;
         if (const char* v = tuning_env("RTX_PRIMARY_PACKET")) c->primary_packet = atoi(v);

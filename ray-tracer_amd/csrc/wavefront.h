@@ -909,56 +909,46 @@ __global__ __launch_bounds__(kBlock) void k_lt_emit(WfPtrs w, DeviceScene sc, Ca
     if (live) w.qa[q] = slot;
 }
 
-// What one depth of a light path leaves for the queues: whether it goes on (its new ray and throughput are in the slot)
-// and whether its vertex asks for a connection to the camera (from hp, to film position (fx, fy), worth cval).
-struct LtShadeOut { bool cont, conn; V3 hp; float fx, fy; C3 cval; };
-// One depth of RayTracer::lightTracePath, RTBase/Renderer.h:336-377, for the light path in `slot` whose ray found hit `h`
-__device__ __forceinline__ void lt_shade_item(const WfPtrs& w, const DeviceScene& sc, const CameraDev& cam, const PassParams& pp, uint32_t slot, const rtx_hit& h, LtShadeOut& out)
-{
-    out.cont = out.conn = false;
-    const rtx_ray r = w.ray[slot];
-    if (h.t < FLT_MAX) {
-        Shading sd; shading_data(sc, h, ld3(r.o), ld3(r.d), sd);
-        if (!(sd.mat->is_light || isPureSpecular(*sd.mat))) {
-            C3 T = ldc(w.T + 3 * slot); const C3 Le = ldc(w.L + 3 * slot);
-            V3 wi = normalize(ld3(cam.origin) - sd.x);
-            C3 col = T * bsdf_evaluate(sc, sd, wi) * Le;
-            out.conn = connect_request(cam, sd.x, sd.sNormal, col, out.fx, out.fy, out.cval); out.hp = sd.x;
-            Rng rng; rng.key = w.key[slot]; rng.dim = w.dim[slot];
-            float rr = wmin(lum(T), 0.9f);
-            if (!(rr < rng.next())) {
-                T = T / rr;
-                C3 bs; float pdf; wi = bsdf_sample(sc, sd, rng, bs, pdf);
-                T = T * bs * fabsf(dot(wi, sd.sNormal)) / pdf;
-                V3 no = sd.x + (wi * kEps);
-                rtx_ray nr; nr.o[0] = no.x; nr.o[1] = no.y; nr.o[2] = no.z; nr.d[0] = wi.x; nr.d[1] = wi.y; nr.d[2] = wi.z;
-                w.ray[slot] = nr; st3(w.T + 3 * slot, T);
-                out.cont = pp.depth + 1 < pp.st.max_bounces;
-            }
-            w.dim[slot] = rng.dim;
-        }
-    }
-}
-
-// lt_shade_item for every live light path of depth pp.depth
+// One depth of RayTracer::lightTracePath, RTBase/Renderer.h:336-377
 // (one queue position per thread; the launch covers every position the queue can have, workgroups beyond its end leave at once)
 __global__ __launch_bounds__(kBlock) void k_lt_shade(WfPtrs w, DeviceScene sc, CameraDev cam, PassParams pp, const uint32_t* __restrict__ qin, uint32_t* qout)
 {
     __shared__ StreamLens s_in;
     const uint32_t extent = stream_load(w.cnt, pp.depth, s_in);
     if (blockIdx.x * (uint32_t)kBlock >= extent) return;
-    const uint32_t i = global_thread();
-    uint32_t slot = 0;
-    LtShadeOut so; so.cont = so.conn = false; so.hp = mk(0, 0, 0); so.fx = so.fy = 0.0f; so.cval = mkc(0, 0, 0);
-    if (i < extent && stream_valid(s_in, i)) {
-        slot = qin[i];
-        const rtx_hit h = w.hit[slot];
-        lt_shade_item(w, sc, cam, pp, slot, h, so);
+    {
+        const uint32_t i = global_thread();
+        bool cont = false, conn = false; uint32_t slot = 0; V3 hp = mk(0, 0, 0); float fx = 0, fy = 0; C3 cval = mkc(0, 0, 0);
+        if (i < extent && stream_valid(s_in, i)) {
+            slot = qin[i];
+            const rtx_hit h = w.hit[slot]; const rtx_ray r = w.ray[slot];
+            if (h.t < FLT_MAX) {
+                Shading sd; shading_data(sc, h, ld3(r.o), ld3(r.d), sd);
+                if (!(sd.mat->is_light || isPureSpecular(*sd.mat))) {
+                    C3 T = ldc(w.T + 3 * slot); const C3 Le = ldc(w.L + 3 * slot);
+                    V3 wi = normalize(ld3(cam.origin) - sd.x);
+                    C3 col = T * bsdf_evaluate(sc, sd, wi) * Le;
+                    conn = connect_request(cam, sd.x, sd.sNormal, col, fx, fy, cval); hp = sd.x;
+                    Rng rng; rng.key = w.key[slot]; rng.dim = w.dim[slot];
+                    float rr = wmin(lum(T), 0.9f);
+                    if (!(rr < rng.next())) {
+                        T = T / rr;
+                        C3 bs; float pdf; wi = bsdf_sample(sc, sd, rng, bs, pdf);
+                        T = T * bs * fabsf(dot(wi, sd.sNormal)) / pdf;
+                        V3 no = sd.x + (wi * kEps);
+                        rtx_ray nr; nr.o[0] = no.x; nr.o[1] = no.y; nr.o[2] = no.z; nr.d[0] = wi.x; nr.d[1] = wi.y; nr.d[2] = wi.z;
+                        w.ray[slot] = nr; st3(w.T + 3 * slot, T);
+                        cont = pp.depth + 1 < pp.st.max_bounces;
+                    }
+                    w.dim[slot] = rng.dim;
+                }
+            }
+        }
+        push_connection(w, conn, kShadowCounterBase + pp.depth, hp, cam, fx, fy, cval);
+        const uint32_t stream = wave_stream();
+        const uint32_t qc = stream_push(cont, w.cnt + stream_word(pp.depth + 1, stream), stream);
+        if (cont) qout[qc] = slot;
     }
-    push_connection(w, so.conn, kShadowCounterBase + pp.depth, so.hp, cam, so.fx, so.fy, so.cval);
-    const uint32_t stream = wave_stream();
-    const uint32_t qc = stream_push(so.cont, w.cnt + stream_word(pp.depth + 1, stream), stream);
-    if (so.cont) qout[qc] = slot;
 }
 
 // Camera connections of one stage: visible ones splat onto the film (Renderer.h:325-331)
@@ -1027,88 +1017,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     LtMixedPolicy pol{sc, w, queue, n_closest, filter, s_live, s_segs};
     __shared__ TailShare<kBlock> ts;
     traverse_dyn<LtMixedPolicy, kModeMixed, COUNT, kRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, COUNT ? 0 : kShare>(sc, stk, n_closest + n_seg, w.cnt + work_index, pol, counters, &ts);
-}
-
-// The late depths of a light-tracing pass in one launch, as k_pt_tail does for the path tracer: a wave takes 64 positions
-// of the live queue of depth pp.depth (their closest hits are known), shades them, walks the camera connections just asked
-// for and the survivors' next rays in one wave-local traversal, shades again, ... Connections that reach the camera splat
-// as they retire (float atomics, as in every other light-tracing kernel).
-struct LtTailLists : TailWaveLists<64> { float fxy[2][64]; };
-struct LtTailPolicy {
-    const DeviceScene& sc; const WfPtrs& w; LtTailLists& t; uint32_t n_live; int filter;
-    __device__ __forceinline__ bool fetch(uint32_t k, float o[3], float d[3], float& maxT, bool& any) const
-    {
-        if (k < n_live) {
-            const rtx_ray r = w.ray[t.live[k]];
-            o[0] = r.o[0]; o[1] = r.o[1]; o[2] = r.o[2]; d[0] = r.d[0]; d[1] = r.d[1]; d[2] = r.d[2]; maxT = 0.0f; any = false;
-        } else {
-            const uint32_t j = k - n_live;
-            const float sg[6] = {t.seg[0][j], t.seg[1][j], t.seg[2][j], t.seg[3][j], t.seg[4][j], t.seg[5][j]};
-            segment_to_ray(sg, o, d, maxT); any = true;
-        }
-        return true;
-    }
-    __device__ __forceinline__ void retire(uint32_t k, const HitRec& best, bool reached) const
-    {
-        if (k < n_live) {
-            const rtx_hit h = make_hit(sc, best);
-            t.hit_id[k] = h.id; t.hit_t[k] = h.t; t.hit_alpha[k] = h.alpha; t.hit_beta[k] = h.beta; t.hit_gamma[k] = h.gamma;
-        } else if (reached && best.pos == 0xFFFFFFFFu) {
-            const uint32_t j = k - n_live;
-            film_splat(w.film, (int)w.W, (int)w.H, filter, t.fxy[0][j], t.fxy[1][j], mkc(t.val[0][j], t.val[1][j], t.val[2][j]));
-        }
-    }
-    __device__ __forceinline__ void note(uint32_t, uint32_t, uint32_t) const {}
-};
-__global__ __launch_bounds__(kBlock) void k_lt_tail(WfPtrs w, DeviceScene sc, CameraDev cam, PassParams pp, const uint32_t* __restrict__ qin, uint32_t task_index, int filter,
-                                                    uint2* spill, uint32_t spill_stride)
-{
-    __shared__ unsigned long long lds[kBlock * kLdsStack];
-    __shared__ TailShare<kBlock> ts;
-    __shared__ StreamLens s_in;
-    __shared__ LtTailLists s_lists[kBlock / 64];
-    LaneStack<kBlock, kLdsStack> stk; stk.init(lds, spill, spill_stride);
-    const uint32_t first_depth = pp.depth;
-    const uint32_t n_tasks = stream_load(w.cnt, first_depth, s_in) / 64u;      // (the only barrier: from here on the waves go their own ways)
-    LtTailLists& t = s_lists[threadIdx.x >> 6];
-    const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (;;) {
-        uint32_t task = 0;
-        if (lane == 0) task = atomicAdd(w.cnt + task_index, 1u);
-        task = (uint32_t)__builtin_amdgcn_readfirstlane((int)task);
-        if (task >= n_tasks) break;
-        uint32_t n_in = 64u;
-        for (pp.depth = first_depth; ; pp.depth++) {
-            bool have; uint32_t slot = 0; rtx_hit h; h.id = 0; h.t = FLT_MAX; h.alpha = h.beta = h.gamma = 0.0f;
-            if (pp.depth == first_depth) {
-                const uint32_t i = task * 64u + lane;
-                have = stream_valid(s_in, i);
-                if (have) { slot = qin[i]; h = w.hit[slot]; }
-            } else {
-                have = lane < n_in;
-                if (have) { slot = t.live[lane]; h.id = t.hit_id[lane]; h.t = t.hit_t[lane]; h.alpha = t.hit_alpha[lane]; h.beta = t.hit_beta[lane]; h.gamma = t.hit_gamma[lane]; }
-            }
-            LtShadeOut so; so.cont = so.conn = false; so.hp = mk(0, 0, 0); so.fx = so.fy = 0.0f; so.cval = mkc(0, 0, 0);
-            if (have) lt_shade_item(w, sc, cam, pp, slot, h, so);
-            const unsigned long long mc = __ballot(so.cont), ms = __ballot(so.conn);
-            const uint32_t n_live = (uint32_t)__popcll(mc), n_seg = (uint32_t)__popcll(ms);
-            if (so.cont) t.live[__popcll(mc & below)] = slot;
-            if (so.conn) {
-                const uint32_t j = (uint32_t)__popcll(ms & below);
-                t.seg[0][j] = so.hp.x; t.seg[1][j] = so.hp.y; t.seg[2][j] = so.hp.z; t.seg[3][j] = cam.origin[0]; t.seg[4][j] = cam.origin[1]; t.seg[5][j] = cam.origin[2];
-                t.val[0][j] = so.cval.r; t.val[1][j] = so.cval.g; t.val[2][j] = so.cval.b; t.fxy[0][j] = so.fx; t.fxy[1][j] = so.fy;
-            }
-            if (n_live + n_seg == 0u) break;
-            // the lists and the slots' new state were written by other lanes than the ones that read them next
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            LtTailPolicy pol{sc, w, t, n_live, filter};
-            traverse_dyn<LtTailPolicy, kModeMixed, false, kTailRefill, kBlock, kLdsStack, kTriUnroll, kLeafLanes, kShare, true>(sc, stk, n_live + n_seg, nullptr, pol, nullptr, &ts);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            if (n_live == 0u) break;                                   // the connections of the paths' last vertices
-            n_in = n_live;
-        }
-    }
 }
 
 // ---- instant radiosity: RTBase/Renderer.h:124-302 -------------------------------------------
@@ -1740,26 +1648,16 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         const dim3 gridS((w.P + 1023u) / 1024u * 4u);       // a thread for every position a streamed queue can have
         // the connections of the light vertices (queue 95) ride with the closest hits of depth 0, those of depth d with the
         // closest hits of depth d + 1; the last ones go alone
-        // from depth c->lt_tail_from on (a few percent of the paths are left) one launch carries every path to its end, see k_lt_tail
-        const uint32_t tail_from = (!cw && c->lt_tail_from != 0u) ? c->lt_tail_from : 0xFFFFFFFFu;
-        bool tail_done = false;
         for (uint32_t d = 0; d < st.max_bounces; d++) {
             pp.depth = d;
             const uint32_t seg_q = (uint32_t)kShadowCounterBase + (d == 0 ? 95u : d - 1u), work = (uint32_t)(kClosestWorkBase + d * kWorkSlotWords);
             if (cw) hipLaunchKernelGGL(k_lt_trace_mixed<true>, gridT, blk, 0, s, w, dscene, d, seg_q, (const uint32_t*)qin, work, (int)st.filter, spill, sstride, ctr);
             else hipLaunchKernelGGL(k_lt_trace_mixed<false>, gridT, blk, 0, s, w, dscene, d, seg_q, (const uint32_t*)qin, work, (int)st.filter, spill, sstride, (unsigned long long*)nullptr);
-            if (d >= tail_from) {
-                hipLaunchKernelGGL(k_lt_tail, dim3(c->resident_lt_tail_blocks), blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, (uint32_t)kShadowWorkBase, (int)st.filter, spill, sstride);
-                tail_done = true;
-                break;
-            }
             hipLaunchKernelGGL(k_lt_shade, gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
             std::swap(qin, qout);
         }
-        if (!tail_done) {
-            const uint32_t last = st.max_bounces > 0 ? st.max_bounces - 1u : 95u;
-            hipLaunchKernelGGL(k_lt_splat, gridT, blk, 0, s, w, dscene, (uint32_t)(kShadowCounterBase + last), (uint32_t)(kShadowWorkBase + last * kWorkSlotWords), (int)st.filter, spill, sstride);
-        }
+        const uint32_t last = st.max_bounces > 0 ? st.max_bounces - 1u : 95u;
+        hipLaunchKernelGGL(k_lt_splat, gridT, blk, 0, s, w, dscene, (uint32_t)(kShadowCounterBase + last), (uint32_t)(kShadowWorkBase + last * kWorkSlotWords), (int)st.filter, spill, sstride);
         c->stats.samples += (uint64_t)w.W * w.H;
     } else {
         // radiosityVplPass, RTBase/Renderer.h:280-302: numThreads x vplRaysPerTile light paths
