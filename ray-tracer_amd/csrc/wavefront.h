@@ -641,10 +641,12 @@ __global__ __launch_bounds__(kBlock) void k_pt_tail(WfPtrs w, DeviceScene sc, Ca
     TailWaveLists<64 * ROUNDS>& t = s_lists[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (;;) {
-        uint32_t task = 0;
-        if (lane == 0) task = atomicAdd(w.cnt + task_index, 1u);
-        task = (uint32_t)__builtin_amdgcn_readfirstlane((int)task);
+    // A wave's first task is the one of its own number; further ones (a queue longer than one round of the grid's waves)
+    // come from a counter. Thousands of waves asking one counter at the start of the launch would be served one after the
+    // other, ~11 ns each: the last wave of the grid would start tens of microseconds late.
+    const uint32_t n_waves = gridDim.x * (uint32_t)(kBlock / 64);
+    uint32_t task = blockIdx.x * (uint32_t)(kBlock / 64) + (threadIdx.x >> 6);
+    for (;; ) {
         if (task >= n_tasks) break;
         uint32_t n_in = kTask;                                          // items to shade at this depth: queue positions first, the live list afterwards
         for (pp.depth = first_depth; ; pp.depth++) {
@@ -688,6 +690,10 @@ __global__ __launch_bounds__(kBlock) void k_pt_tail(WfPtrs w, DeviceScene sc, Ca
             n_in = n_live;
         }
         RTX_PACKET_STATS(n_tasks_done++;)
+        if (n_tasks <= n_waves) break;                                  // (every task had a wave of its own)
+        uint32_t next = 0;
+        if (lane == 0) next = atomicAdd(w.cnt + task_index, 1u);
+        task = n_waves + (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
     }
     // (tuning build: clock ticks per wave in shade steps and in traversals, waves with a task, their tasks and rounds, the longest wave)
     RTX_PACKET_STATS(if (stats && lane == 0 && n_tasks_done) { atomicAdd(&stats[16], t_shade); atomicAdd(&stats[17], t_trace); atomicAdd(&stats[18], 1ull); atomicAdd(&stats[19], (unsigned long long)n_tasks_done);
