@@ -40,7 +40,7 @@ constexpr int kClosestWorkBase = 192 * kQueueStride;                        // 9
 constexpr int kShadowWorkBase = kClosestWorkBase + 96 * kWorkSlotWords;     // 96 slots of the shadow / splat launches
 // Path tracing keeps every queue behind depth 0 as kQueueStreams streams with a length of their own (see stream_push):
 // queue q, stream c at word stream_word(q, c), a line each like the dense queue lengths
-constexpr int kQueueStreams = 64;
+constexpr int kQueueStreams = 16;
 constexpr int kStreamCounterBase = kShadowWorkBase + 96 * kWorkSlotWords;
 constexpr int kCounterWords = kStreamCounterBase + 192 * kQueueStreams * kQueueStride;
 constexpr int kQueueSlack = kQueueStreams * 64;                             // queue arrays hold P + kQueueSlack entries: streamed queues round up to whole blocks of 64 per stream
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         ShadeOut so; so.cont = so.shadow = false; so.sx = so.p2 = mk(0, 0, 0); so.sval = mkc(0, 0, 0);
         if (have) pt_shade_item<FIRST>(w, sc, cam, pp, slot, h, so);
         cont = so.cont; shadow = so.shadow; p2 = so.p2; sval = so.sval; sx = so.sx;
-        const uint32_t stream = ((blockIdx.x % (uint32_t)(kQueueStreams / 4)) << 2) | (((threadIdx.x >> 6) + blockIdx.x / (uint32_t)(kQueueStreams / 4)) & 3u);
+        const uint32_t stream = ((blockIdx.x & 3u) << 2) | (((threadIdx.x >> 6) + (blockIdx.x >> 2)) & 3u);
         const uint32_t qs = stream_push(shadow, w.cnt + stream_word(kShadowCounterBase + pp.depth, stream), stream);
         if (shadow) {
             float* s = w.sseg + 6 * (size_t)qs; s[0] = sx.x; s[1] = sx.y; s[2] = sx.z; s[3] = p2.x; s[4] = p2.y; s[5] = p2.z;
@@ -868,7 +868,7 @@ __device__ __forceinline__ bool connect_request(const CameraDev& cam, V3 p, V3 n
 }
 
 // the stream the calling wave appends to (wave w of workgroup b: see k_pt_shade)
-__device__ __forceinline__ uint32_t wave_stream() { return ((blockIdx.x % (uint32_t)(kQueueStreams / 4)) << 2) | (((threadIdx.x >> 6) + blockIdx.x / (uint32_t)(kQueueStreams / 4)) & 3u); }
+__device__ __forceinline__ uint32_t wave_stream() { return ((blockIdx.x & 3u) << 2) | (((threadIdx.x >> 6) + (blockIdx.x >> 2)) & 3u); }
 
 // every lane of the wave calls this from uniform control flow (a streamed queue: one atomic per wave, no barrier)
 __device__ __forceinline__ void push_connection(const WfPtrs& w, bool want, uint32_t queue, V3 p, const CameraDev& cam, float x, float y, C3 value)
@@ -1600,7 +1600,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         // hits of depth d (neither depends on the other, and a traversal launch lasts at least as long as its slowest
         // ray), shade(d); the launch of depth max_bounces + 1 has the shadow rays of the last depth only.
         // A shade launch has a thread for every position a queue can have (streamed queues, see stream_push).
-        const dim3 gridS((w.P + (uint32_t)kQueueSlack - 1u) / (uint32_t)kQueueSlack * (uint32_t)(kQueueStreams / 4));
+        const dim3 gridS((w.P + 1023u) / 1024u * 4u);
         auto mixed = [&](uint32_t d, const uint32_t* queue) {
             if (cw) hipLaunchKernelGGL(k_pt_trace_mixed<true>, gridT, blk, 0, s, w, dscene, d, queue, (uint32_t)(kClosestWorkBase + d * kWorkSlotWords), spill, sstride, ctr);
             else hipLaunchKernelGGL(k_pt_trace_mixed<false>, gridT, blk, 0, s, w, dscene, d, queue, (uint32_t)(kClosestWorkBase + d * kWorkSlotWords), spill, sstride, (unsigned long long*)nullptr);
@@ -1651,7 +1651,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
     } else if (st.algorithm == RTX_AL_LIGHT_TRACE) {
         hipLaunchKernelGGL(k_lt_emit, gridP, blk, 0, s, w, dscene, c->dcam, pp);
         uint32_t* qin = w.qa; uint32_t* qout = w.qb;
-        const dim3 gridS((w.P + (uint32_t)kQueueSlack - 1u) / (uint32_t)kQueueSlack * (uint32_t)(kQueueStreams / 4));       // a thread for every position a streamed queue can have
+        const dim3 gridS((w.P + 1023u) / 1024u * 4u);       // a thread for every position a streamed queue can have
         // the connections of the light vertices (queue 95) ride with the closest hits of depth 0, those of depth d with the
         // closest hits of depth d + 1; the last ones go alone
         for (uint32_t d = 0; d < st.max_bounces; d++) {
