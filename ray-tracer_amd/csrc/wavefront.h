@@ -917,17 +917,28 @@ __global__ __launch_bounds__(kBlock) void k_lt_emit(WfPtrs w, DeviceScene sc, Ca
 
 // One depth of RayTracer::lightTracePath, RTBase/Renderer.h:336-377
 // (one queue position per thread; the launch covers every position the queue can have, workgroups beyond its end leave at once)
+// REGROUP: the workgroup sorts its items by class first, as the path tracer's shade kernel does (light paths land all
+// over the scene from their first vertex on, so every depth is a mix of materials)
+template <bool REGROUP>
 __global__ __launch_bounds__(kBlock) void k_lt_shade(WfPtrs w, DeviceScene sc, CameraDev cam, PassParams pp, const uint32_t* __restrict__ qin, uint32_t* qout)
 {
+    __shared__ ShadeRegroup s_regroup;
     __shared__ StreamLens s_in;
     const uint32_t extent = stream_load(w.cnt, pp.depth, s_in);
     if (blockIdx.x * (uint32_t)kBlock >= extent) return;
     {
         const uint32_t i = global_thread();
         bool cont = false, conn = false; uint32_t slot = 0; V3 hp = mk(0, 0, 0); float fx = 0, fy = 0; C3 cval = mkc(0, 0, 0);
-        if (i < extent && stream_valid(s_in, i)) {
-            slot = qin[i];
-            const rtx_hit h = w.hit[slot]; const rtx_ray r = w.ray[slot];
+        bool have = i < extent && stream_valid(s_in, i);
+        rtx_hit h; h.id = 0; h.t = FLT_MAX; h.alpha = h.beta = h.gamma = 0.0f;
+        if (have) { slot = qin[i]; h = w.hit[slot]; }
+        if constexpr (REGROUP) {
+            uint32_t cls = kClassMiss;
+            if (have && h.t < FLT_MAX) cls = sc.shade[h.id].shade_class;
+            have = regroup_by_class(s_regroup, have, cls, slot, h);
+        }
+        if (have) {
+            const rtx_ray r = w.ray[slot];
             if (h.t < FLT_MAX) {
                 Shading sd; shading_data(sc, h, ld3(r.o), ld3(r.d), sd);
                 if (!(sd.mat->is_light || isPureSpecular(*sd.mat))) {
@@ -1659,7 +1670,8 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
             const uint32_t seg_q = (uint32_t)kShadowCounterBase + (d == 0 ? 95u : d - 1u), work = (uint32_t)(kClosestWorkBase + d * kWorkSlotWords);
             if (cw) hipLaunchKernelGGL(k_lt_trace_mixed<true>, gridT, blk, 0, s, w, dscene, d, seg_q, (const uint32_t*)qin, work, (int)st.filter, spill, sstride, ctr);
             else hipLaunchKernelGGL(k_lt_trace_mixed<false>, gridT, blk, 0, s, w, dscene, d, seg_q, (const uint32_t*)qin, work, (int)st.filter, spill, sstride, (unsigned long long*)nullptr);
-            hipLaunchKernelGGL(k_lt_shade, gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
+            if (c->lt_regroup) hipLaunchKernelGGL(k_lt_shade<true>, gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
+            else hipLaunchKernelGGL(k_lt_shade<false>, gridS, blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, qout);
             std::swap(qin, qout);
         }
         const uint32_t last = st.max_bounces > 0 ? st.max_bounces - 1u : 95u;
