@@ -1711,7 +1711,7 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(1024), 0, s, w, pp);
         hipLaunchKernelGGL(k_raygen, gridP, blk, 0, s, w, c->dcam, pp);
         closest_primary();
-        hipLaunchKernelGGL(k_ir_prepare, gridP, blk, 0, s, w, dscene, pp);
+        hipLaunchKernelGGL(k_ir_prepare, gridQ, blk, 0, s, w, dscene, pp);
         hipLaunchKernelGGL(k_ir_bounds, dim3(w.P / 256u), blk, 0, s, w, c->ir_block_cull ? 0 : 1);
         for (uint32_t bi = 0; bi < std::max(batches, 1u); bi++) {
             const uint32_t v0 = bi * vb, work = (uint32_t)(kShadowWorkBase + bi * kWorkSlotWords);
