@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--only", default="", choices=["", "headline", "extras", "pathtrace"], help="profiling: run the headline leg plus only this part")
     ap.add_argument("--pt-spp", type=int, default=64, help="passes of the path-trace side measurement PER RANK (weak scaling: N ranks render N x this)")
     ap.add_argument("--pt-total-spp", type=int, default=0, help="path-trace leg with this many passes IN TOTAL, split over the ranks (strong scaling); overrides --pt-spp")
-    ap.add_argument("--no-radiosity", action="store_true", help="skip the instant-radiosity side measurement")
+    ap.add_argument("--no-radiosity", action="store_true", help="skip the light-tracing and instant-radiosity side measurements")
     ap.add_argument("--variants", default="", help="A/B: comma list of RTX_VARIANT values, interleaved rounds in one process")
     ap.add_argument("--ab-env", default="", help="A/B: NAME=v1,v2,... varies this tuning switch instead of RTX_VARIANT (which stays at the first --variants value)")
     ap.add_argument("--ab-scene", default="soup", choices=["soup", "mixed"])
@@ -563,10 +563,33 @@ def pathtrace_side(pkg, scenes, lib, core, torch, dist, world, rank, dev, args, 
             out["pathtrace_ms_one_pass_per_call"] = round((time.perf_counter() - t1) / 16 * 1e3, 4)
             out["pathtrace_roofline"] = pathtrace_roofline(core, dt / total, prof)
             if not args.no_radiosity:
+                out["light_tracing"] = light_tracing_side(pkg, core, args)
                 out["instant_radiosity"] = radiosity_side(pkg, core, args)
         return out
     except pkg.RtxError as e:
         return {"pathtrace_spp_per_s": None, "pathtrace_error": str(e)}
+
+
+def light_tracing_side(pkg, core, args):
+    """Light tracing (RayTracer::lightTrace, RTBase/Renderer.h:379-411) on the scene the core holds: one light path per
+    pixel slot and pass, every vertex connected to the camera. Passes per second with passes in flight and the
+    milliseconds of a pass when the host asks for one per call; rays per pass from two instrumented passes."""
+    core.set_settings(pkg.make_settings(algorithm=pkg.AL_LIGHT_TRACE, total_spp=1 << 20, max_bounces=5, seed=1))
+    core.clear(); core.render_passes(3); core.clear()
+    passes = 64
+    t0 = time.perf_counter()
+    core.render_passes(passes)
+    dt = (time.perf_counter() - t0) / passes
+    core.clear()
+    t0 = time.perf_counter()
+    for _ in range(16):
+        core.render_passes(1)
+    single = (time.perf_counter() - t0) / 16
+    core.clear()
+    w = core.count_render_work(2)
+    return {"passes_per_s": round(1.0 / dt, 1), "ms_per_pass": round(dt * 1e3, 4), "ms_per_pass_one_in_flight": round(single * 1e3, 4),
+            "closest_rays_per_pass": w["closest_rays"] / 2, "connection_rays_per_pass": w["shadow_rays"] / 2,
+            "mrays_per_s": round((w["closest_rays"] + w["shadow_rays"]) / 2 / dt / 1e6, 1), "resolution": [args.width, args.height]}
 
 
 def radiosity_side(pkg, core, args):
