@@ -57,7 +57,6 @@ struct WfPtrs {
     float* sseg;       // [P][6] shadow segment p1 -> p2
     float* sval;       // [P][3] contribution carried by the shadow ray
     float* sxy;        // [P][2] splat position (light tracing)
-    rtx_ray* qray;     // [P]    path tracing: the ray of the path at a queue position, beside its slot in the queue (a traversal launch then fetches a ray with one load instead of slot, then ray)
     uint32_t* spath;   // [P]    path slot the contribution belongs to
     float* vpl;        // [V][10] x(3) n(3) Le(3) valid, slot j * (maxBounces + 1) + d of light path j
     float* vplc;       // [<= V][10] the valid ones, packed in list order
@@ -73,7 +72,7 @@ struct WfPtrs {
 };
 
 struct WavefrontBuffers {
-    DevBuf ray, hit, T, L, xy, key, dim, mis, flags, qa, qb, cnt, sseg, sval, sxy, spath, vpl, vpl_total, tile_off, ir_vis, ir_bounds, qray;
+    DevBuf ray, hit, T, L, xy, key, dim, mis, flags, qa, qb, cnt, sseg, sval, sxy, spath, vpl, vpl_total, tile_off, ir_vis, ir_bounds;
     WfPtrs p{};
     uint32_t vpl_capacity = 0;
     bool cnt_clean = false;      // the last pass on these buffers zeroed the counters itself when it was done with them (path tracing, box filter)
@@ -375,7 +374,7 @@ __device__ __forceinline__ bool regroup_by_class(ShadeRegroup& s, bool active, u
 
 // What shading one path leaves for the queues: whether it goes on (its new ray and state are in the slot) and whether
 // it asks for a shadow ray (segment sx -> p2, value sval the path gains if the segment is free).
-struct ShadeOut { bool cont, shadow; V3 sx, p2; C3 sval; rtx_ray next; };
+struct ShadeOut { bool cont, shadow; V3 sx, p2; C3 sval; };
 // One depth of RayTracer::pathTrace, RTBase/Renderer.h:476-526, for the path in `slot` whose ray found hit `h`.
 // FIRST: depth 0, the path's state is the camera sample of the slot (nothing stored yet).
 template <bool FIRST>
@@ -419,7 +418,7 @@ __device__ __forceinline__ void pt_shade_item(const WfPtrs& w, const DeviceScene
                     T = T * bs * fabsf(dot(wi, sd.sNormal)) / pdf;
                     V3 no = sd.x + (wi * kEps);
                     rtx_ray nr; nr.o[0] = no.x; nr.o[1] = no.y; nr.o[2] = no.z; nr.d[0] = wi.x; nr.d[1] = wi.y; nr.d[2] = wi.z;
-                    w.ray[slot] = nr; out.next = nr; st3(w.T + 3 * slot, T); w.mis[slot] = pdf;
+                    w.ray[slot] = nr; st3(w.T + 3 * slot, T); w.mis[slot] = pdf;
                     w.flags[slot] = (flags & ~kFlagCanHitLight) | (isPureSpecular(*sd.mat) ? kFlagCanHitLight : 0u);
                     if constexpr (FIRST) w.key[slot] = rkey;
                     cont = true;
@@ -487,7 +486,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             st3(w.sval + 3 * (size_t)qs, sval); w.spath[qs] = slot;
         }
         const uint32_t qc = stream_push(cont, w.cnt + stream_word(pp.depth + 1, stream), stream);
-        if (cont) { qout[qc] = slot; if (w.qray) w.qray[qc] = so.next; }
+        if (cont) qout[qc] = slot;
     }
 }
 
@@ -545,7 +544,7 @@ struct PtMixedPolicy {
         if (k < n_closest) {
             any = false;
             if (!stream_valid(live, k)) return false;              // a hole of the streamed queue
-            const rtx_ray r = w.qray ? w.qray[k] : w.ray[queue[k]];
+            const rtx_ray r = w.ray[queue[k]];
             o[0] = r.o[0]; o[1] = r.o[1]; o[2] = r.o[2]; d[0] = r.d[0]; d[1] = r.d[1]; d[2] = r.d[2];
         } else {
             any = true;
@@ -1476,14 +1475,14 @@ inline int wavefront_alloc(rtx_ctx* c, int lane, const rtx_settings& st)
     RTX_ENS(b.xy, P * 8); RTX_ENS(b.key, P * 4); RTX_ENS(b.dim, P * 4); RTX_ENS(b.mis, P * 4); RTX_ENS(b.flags, P * 4);
     const size_t Q = P + kQueueSlack;      // what is indexed by queue position
     RTX_ENS(b.qa, Q * 4); RTX_ENS(b.qb, Q * 4); RTX_ENS(b.cnt, kCounterWords * 4);
-    RTX_ENS(b.sseg, Q * 24); RTX_ENS(b.sval, Q * 12); RTX_ENS(b.sxy, Q * 8); RTX_ENS(b.qray, Q * sizeof(rtx_ray)); RTX_ENS(b.spath, Q * 4); RTX_ENS(b.vpl_total, 16); RTX_ENS(b.tile_off, P / 256 * 4);
+    RTX_ENS(b.sseg, Q * 24); RTX_ENS(b.sval, Q * 12); RTX_ENS(b.sxy, Q * 8); RTX_ENS(b.spath, Q * 4); RTX_ENS(b.vpl_total, 16); RTX_ENS(b.tile_off, P / 256 * 4);
     if (st.algorithm == RTX_AL_INSTANT_RADIOSITY) RTX_ENS(b.ir_bounds, P / 256 * 48);
 #undef RTX_ENS
     WfPtrs& p = b.p;
     p.ray = b.ray.as<rtx_ray>(); p.hit = b.hit.as<rtx_hit>(); p.T = b.T.as<float>(); p.L = b.L.as<float>(); p.xy = b.xy.as<float>();
     p.key = b.key.as<uint32_t>(); p.dim = b.dim.as<uint32_t>(); p.mis = b.mis.as<float>(); p.flags = b.flags.as<uint32_t>();
     p.qa = b.qa.as<uint32_t>(); p.qb = b.qb.as<uint32_t>(); p.cnt = b.cnt.as<uint32_t>();
-    p.sseg = b.sseg.as<float>(); p.sval = b.sval.as<float>(); p.sxy = b.sxy.as<float>(); p.qray = c->queue_rays ? b.qray.as<rtx_ray>() : nullptr; p.spath = b.spath.as<uint32_t>();
+    p.sseg = b.sseg.as<float>(); p.sval = b.sval.as<float>(); p.sxy = b.sxy.as<float>(); p.spath = b.spath.as<uint32_t>();
     p.vpl_total = b.vpl_total.as<uint32_t>(); p.tile_off = b.tile_off.as<uint32_t>(); p.ir_bounds = b.ir_bounds.as<float>();
     p.film = c->b_film.as<float>(); p.tile_samples = c->b_tile_samples.as<uint32_t>();
     p.P = (uint32_t)n_local * 256u; p.W = (uint32_t)c->cam.width; p.H = (uint32_t)c->cam.height; p.tiles_x = c->tiles_x; p.n_tiles = n_tiles;
