@@ -91,6 +91,7 @@ struct rtx_ctx {
     uint32_t* depth_stats = nullptr;                   // pinned host memory the path tracer's last kernel reports its queue sizes per depth to (see publish_depth_stats)
     bool ir_block_cull = true;                         // instant radiosity: (block of 256 gather points, VPL) pairs are skipped whole where their bounds allow it (RTX_IR_BLOCK_CULL)
     bool lt_regroup = true;                            // light tracing: shade items sorted by class inside a workgroup (RTX_LT_REGROUP)
+    int tail_grid_limit = 0;                           // (tuning build, RTX_TAIL_GRID) at most this many workgroups for the tail kernel, 0 = as many as fit
     int tail_rounds = 0;                               // blocks of 64 queue positions a wave of the tail kernel takes at a time: 1, 2, or 0 = by the passes in flight (RTX_TAIL_ROUNDS)
     bool tail_stats = false;                           // (tuning build, RTX_DEBUG_COUNTERS) the tail kernel times its phases, the packet gather counts its steps
     int resident_tail_blocks[2] = {256, 256};          // workgroups of that kernel the device holds at once, by blocks per wave (1, 2)

@@ -235,6 +235,7 @@ static int create_resources(rtx_ctx* c, int device)
     if (const char* v = tuning_env("RTX_PIPELINE")) c->pipeline = std::max(0, std::min(kPipeline, atoi(v)));
     c->tail_stats = tuning_env("RTX_DEBUG_COUNTERS") != nullptr;
     if (const char* v = tuning_env("RTX_LT_REGROUP")) c->lt_regroup = atoi(v) != 0;
+    if (const char* v = tuning_env("RTX_TAIL_GRID")) c->tail_grid_limit = std::max(0, atoi(v));
     if (const char* v = tuning_env("RTX_TAIL_FROM")) c->tail_from_depth = (uint32_t)std::max(0, atoi(v));
     if (const char* v = tuning_env("RTX_REGROUP_FROM")) c->regroup_from_depth = (uint32_t)std::max(0, atoi(v));
     HIP_TRY(hipHostMalloc((void**)&c->depth_stats, 96 * sizeof(uint32_t), hipHostMallocDefault));

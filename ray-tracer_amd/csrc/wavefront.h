@@ -1623,11 +1623,11 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
         // (a wave takes two blocks of 64 positions at a time when passes overlap, one when this pass has the device to itself:
         //  fuller lanes per instruction help the former, more waves the latter)
         const int tail_rounds = c->tail_rounds ? c->tail_rounds : (c->passes_in_flight > 1 ? 2 : 1);
-        const int tail_blocks = c->resident_tail_blocks[tail_rounds - 1];
+        const int tail_blocks_fit = c->resident_tail_blocks[tail_rounds - 1];
         uint32_t tail_from = 0xFFFFFFFFu;
         if (!cw && c->tail_from_depth != 0u && c->depth_stats) {
             const volatile uint32_t* ds = c->depth_stats;
-            const uint32_t fits = (uint32_t)tail_blocks * (uint32_t)(kBlock / 64) * 64u * (uint32_t)tail_rounds;
+            const uint32_t fits = (uint32_t)tail_blocks_fit * (uint32_t)(kBlock / 64) * 64u * (uint32_t)tail_rounds;
             for (uint32_t d = std::max(1u, c->tail_from_depth); d <= st.max_bounces && d < 96u; d++) if (ds[d] <= fits) { tail_from = d; break; }
         }
         bool tail_done = false;
@@ -1636,6 +1636,8 @@ inline int wavefront_render_pass(rtx_ctx* c, int lane, hipStream_t s, hipEvent_t
             if (d >= tail_from) {
                 mixed(d, qin);
                 RTX_PACKET_STATS(unsigned long long* stats = c->tail_stats ? c->b_counters.as<unsigned long long>() : nullptr;)
+                // (RTX_TAIL_GRID, tuning build: fewer workgroups than the queue was sized for, so that waves take several tasks)
+                const int tail_blocks = c->tail_grid_limit > 0 ? std::min(tail_blocks_fit, c->tail_grid_limit) : tail_blocks_fit;
                 if (tail_rounds == 2) hipLaunchKernelGGL(k_pt_tail<2>, dim3(tail_blocks), blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, (uint32_t)kShadowWorkBase, spill, sstride RTX_PACKET_STATS(, stats));
                 else hipLaunchKernelGGL(k_pt_tail<1>, dim3(tail_blocks), blk, 0, s, w, dscene, c->dcam, pp, (const uint32_t*)qin, (uint32_t)kShadowWorkBase, spill, sstride RTX_PACKET_STATS(, stats));
                 tail_done = true;

@@ -506,14 +506,16 @@ def test_tail_kernel_and_regrouping_leave_the_film_bit_identical(pkg, lib, lib_t
     """The path tracer's late depths run in one launch (a wave carries 64 paths to their ends, 128 when passes overlap) once a pass has reported
     queue sizes, and its shade kernels sort their items by class inside a workgroup. Both are schedules: every path
     computes and sums what it would as a plain wavefront. 640x360 mixed-material scene under the environment map with
-    MIS, 12 passes, one per call (the report of pass k is there for pass k + 1) and four per call; the shipped library
-    against the tuning build with both switched off. Only the box filter's strays (atomic adds) may differ."""
+    MIS, 12 passes, one per call (the report of pass k is there for pass k + 1) and four per call, and with the tail
+    kernel held to 24 workgroups (96 waves for a few hundred tasks: the task counter behind a wave's first task); the
+    shipped library against the tuning build with both switched off. Only the box filter's strays (atomic adds) may differ."""
     scene, cam_kw = scenes.mixed_scene(48), scenes.mixed_camera()
     st = pkg.make_settings(total_spp=12, max_bounces=5, use_mis=1, seed=21)
     films = {}
     for name, which, env, per_call in (("shipped, one pass per call", lib, {}, 1), ("shipped, four passes per call", lib, {}, 4),
+                                       ("tail kernel on 24 workgroups: several tasks per wave", lib_tuning, {"RTX_TAIL_GRID": "24"}, 1),
                                        ("plain wavefront", lib_tuning, {"RTX_TAIL_FROM": "0", "RTX_REGROUP_FROM": "99"}, 1)):
-        for k in ("RTX_TAIL_FROM", "RTX_REGROUP_FROM"): monkeypatch.delenv(k, raising=False)
+        for k in ("RTX_TAIL_FROM", "RTX_REGROUP_FROM", "RTX_TAIL_GRID"): monkeypatch.delenv(k, raising=False)
         for k, v in env.items(): monkeypatch.setenv(k, v)
         c = pkg.Core(0, which)              # the switches are read when a context is created
         c.upload_scene(scene); c.set_camera(pkg.look_at(which, width=640, height=360, **cam_kw)); c.set_settings(st); c.clear()
